@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NTT polynomial multiplication at product length 2^18 on MI355X.
+
+Workload (BASELINE.json configs[1]): single 32-bit prime 469762049, n = 2^17 coefficients
+per input (product length L = 2^18), a batch of independent multiplications resident in
+HBM.  A "step" is one pass of the hot path over the whole batch (batch multiplications).
+With N GPUs every rank runs its own batch (weak scaling, no data-path collective).
+
+Prints ONE JSON line (rank 0).  `value` = poly-mults/s over all ranks.  `roofline` is for
+the dominant kernel, timed live with HIP events on the launch stream; `cpu_baseline` is the
+compiled reference program (oracle/_ref/ref_main = main.cc) timed on this host.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P = 469762049
+LOG_L = 18
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+# algorithmic HBM bytes per multiplication, per kernel (u32 words of length L moved once):
+#   col_fwd reads a,b and writes both transformed copies  -> 4 L words
+#   row_mul reads both copies and writes the product rows -> 3 L words
+#   col_inv reads and writes the product                  -> 2 L words
+KERNEL_WORDS = {"col_fwd": 4, "row_mul": 3, "col_inv": 2}
+MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per multiplication
+
+
+def cpu_baseline(n, p, reps=3):
+    """Time the reference CPU program itself on this host (its own chrono line)."""
+    from oracle import pyoracle as po
+    O = po.Oracle()
+    cores = O.max_threads()
+    cases = [([1, 5, 5, 4], [4, 1, 5, 2], 7340033)]
+    for k in range(4):
+        cases.append((O.fill_random(n, 1001 + k, p), O.fill_random(n, 2001 + k, p), p))
+    if po.have_ref():
+        _, lat, _ = po.run_ref_main(cases, which="ref_main", reps=reps)
+        ms = [x for k in (1, 2, 3, 4) for x in lat.get(k, [])]
+        kind = "reference"
+        what = (f"oracle/_ref/ref_main (main.cc: Barrett, 4-prime CRT, OpenMP): {len(ms)} multiplications, "
+                f"n={n}, p={p}, its own timed block (alloc+split+4 NTT products+CRT), median")
+    else:
+        ms = []
+        for k in range(1, 5):
+            t0 = time.perf_counter()
+            O.poly_multiply_crt(cases[k][0], cases[k][1], p)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        kind = "port"
+        what = f"oracle/ntt_oracle.c restatement of main.cc, {len(ms)} multiplications, n={n}, p={p}, median"
+    med = statistics.median(ms)
+    return {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "sample": what,
+            "ms_per_mult": med, "note": "the reference's NTT stage uses at most 4 threads (one per CRT prime, main.cc:306)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="multiplications per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import ntt_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ntt_amd.init(local_rank)
+
+    L, n, B = 1 << LOG_L, 1 << (LOG_L - 1), args.batch
+    # synthetic inputs, generated on the device: uniform in [0, p), upper half zero (padding)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    a = torch.zeros((B, L), dtype=torch.int32, device=dev)
+    b = torch.zeros((B, L), dtype=torch.int32, device=dev)
+    a[:, :n] = torch.randint(0, P, (B, n), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    b[:, :n] = torch.randint(0, P, (B, n), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    c = torch.empty_like(a)
+    ntt_amd.reserve(L, B, 1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ntt_amd.dev_cyclic_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), L, P, B, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # spot-check one product of the batch against the oracle before timing anything
+    if rank == 0:
+        from oracle import pyoracle as po
+        O = po.Oracle()
+        ah = a[0].cpu().numpy().view(np.uint32)
+        bh = b[0].cpu().numpy().view(np.uint32)
+        want = O.ntt_compute(ah, bh, P)
+        got = c[0].cpu().numpy().view(np.uint32)
+        if not np.array_equal(got, want):
+            print(json.dumps({"error": "GPU result differs from the oracle"}))
+            sys.exit(1)
+
+    ntt_amd.profile_reset()
+    ntt_amd.profile_enable(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ntt_amd.profile_enable(False)
+    prof = ntt_amd.profile_read()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        mults = world * B * args.steps
+        value = mults / elapsed
+        butterflies = 3 * (L // 2) * LOG_L
+        kern = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max(kern, key=lambda k: kern[k][0])
+        dom_ms, dom_launches = kern[dom]
+        dom_avg_s = dom_ms / dom_launches * 1e-3
+        dom_bytes = KERNEL_WORDS.get(dom, 0) * 4 * L * B
+        achieved = dom_bytes / dom_avg_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        model_gbs = MODEL_BYTES_PER_L * L * (value / world) / 1e9
+        out = {
+            "metric": "poly-mults/sec at product length 2^18 (single 32-bit prime)",
+            "value": value,
+            "unit": "poly-mults/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: single prime 469762049, product length 2^18 (n=2^17 per input), "
+                                   "Montgomery LDS-fused NTT, batch resident in HBM",
+                       "p": P, "log2_len": LOG_L, "batch_per_gpu": B, "passes": ntt_amd.plan_info(L),
+                       "parallelism": f"batch-sharded x{world}, no collective"},
+            "ns_per_butterfly": elapsed / (mults / world) / butterflies * 1e9,
+            "us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms / dom_launches},
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()},
+            "pipeline_model": {"bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "achieved_GBs_per_gpu": model_gbs,
+                               "frac_of_peak": model_gbs / HBM_PEAK_GBS,
+                               "bytes_per_mult_moved": 36 * L},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(n, P)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ntt_amd.shutdown()
+
+
+if __name__ == "__main__":
+    main()

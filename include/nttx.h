@@ -1,0 +1,120 @@
+/* nttx — C ABI of the MI355X NTT polynomial-multiplication engine (libnttx.so).
+ *
+ * The reference has no library boundary: its hot path is the timed block between
+ * fRead and fCheck in each program's main() (main.cc:283-341, main_pthread.cc:386-475,
+ * monttry2.cpp:385-393, pthread_normal.cpp:450-461) plus the harness-declared entry
+ * point  void poly_multiply(int *a, int *b, int *ab, int n, int p)
+ * (monttry2.cpp:344-350, pthread_normal.cpp:352-358).  Each function below names the
+ * reference code it stands in for.
+ *
+ * Conventions: every function returns 0 on success or a negative NTTX_E* code and
+ * never throws; nttx_last_error() returns a message for the calling thread's last
+ * failure.  Calls are synchronous unless a stream argument says otherwise.  Host
+ * buffers are caller-owned; nothing is retained after a call returns.  All calls
+ * of one process are serialised on an internal mutex.
+ */
+#ifndef NTTX_H
+#define NTTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTTX_OK 0
+#define NTTX_EINVAL (-1)   /* bad argument (n <= 0, null pointer, p < 2, ...) */
+#define NTTX_ERANGE (-2)   /* exact result not representable: n*(p-1)^2 >= product of CRT primes, or length unsupported */
+#define NTTX_EDEVICE (-3)  /* HIP runtime failure */
+#define NTTX_ENOINIT (-4)  /* nttx_init has not been called */
+
+/* Which arithmetic path a (p, n) pair takes. */
+#define NTTX_PATH_DIRECT32 0 /* one NTT modulo p itself: p < 2^31 prime, 2^k | p-1 (monttry2.cpp get_result) */
+#define NTTX_PATH_CRT4 1     /* four 32-bit NTT primes + CRT (main.cc:245-338) */
+
+/* Select the GPU of this process and build the context (one process per GPU).
+ * No counterpart in the reference (CPU-only program start-up, main.cc:230-270 builds
+ * the Barrett/CRT constants once per process; so does this). */
+int nttx_init(int device);
+void nttx_shutdown(void);
+const char *nttx_last_error(void);
+
+/* Path that nttx_poly_multiply_u64 / _i32 will take for this modulus and length. */
+int nttx_path_for(uint64_t p, int n);
+
+/* ab[0 .. 2n-2] = a * b mod p, canonical.  Harness entry point with (T,P) = (int,int):
+ * poly_multiply monttry2.cpp:344-350 as used by main() monttry2.cpp:375-393
+ * (toMont, get_result, fromMont) and pthread_normal.cpp:440-461. */
+int nttx_poly_multiply_i32(const int32_t *a, const int32_t *b, int32_t *ab, int n, int32_t p);
+
+/* Same for (T,P) = (uint64_t,int64_t): the timed block of main.cc:283-341 /
+ * main_pthread.cc:386-475 (residue split, 4 x ntt_compute_omp, CRT, mod p).
+ * Takes the direct single-prime path when p allows it, the 4-prime CRT path otherwise. */
+int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
+
+/* Force the 4-prime CRT path (main.cc:286-338) whatever p is. */
+int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
+
+/* batch independent products: a, b are [batch][n], ab is [batch][2n-1]; p < 2^31 on the
+ * direct path.  No counterpart in the reference (one product per call). */
+int nttx_poly_multiply_batch_u32(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch);
+
+/* In-place length-len transform, natural order in and out, no 1/len scaling:
+ * ntt_iter_barrett(a, p, root = 3, invert) main.cc:143-182.  len a power of two dividing p-1. */
+int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse);
+
+/* One single-prime cyclic convolution of zero-padded residue vectors, host buffers of len
+ * words each: ntt_compute_omp main.cc:185-209 / ntt_thread_func main_pthread.cc:266-290. */
+int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, int len, uint32_t p);
+
+/* CRT recombination alone, host buffers: res[k] are the four residue vectors (len words,
+ * moduli 469762049, 998244353, 1004535809, 1224736769), ab[i] = x_i mod p for i < nout.
+ * main.cc:313-338 / crt_thread_func main_pthread.cc:293-310. */
+int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, int nout, uint64_t p);
+
+/* ---- device-resident variants (benchmarks, pipelines that keep data in HBM) ---------- */
+
+/* d_c[b] = cyclic product of d_a[b] and d_b[b]; all three are [batch][len] u32 in device
+ * memory, inputs canonical (< p) and zero-padded by the caller, outputs canonical.
+ * Inputs are left untouched.  Asynchronous on `stream` (a hipStream_t, NULL = default). */
+int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch,
+                                 void *stream);
+
+/* d_ab[b][0..2n-2] = a*b mod p through the 4-prime CRT path; d_a, d_b are [batch][n] u64,
+ * d_ab is [batch][2n-1] u64, all device memory.  Asynchronous on `stream`. */
+int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch,
+                              void *stream);
+
+/* In-place batched transform on device memory, [batch][len]; bit_reversed_out != 0 skips
+ * the final permutation (forward output stays in bit-reversed order). */
+int nttx_dev_ntt_u32(void *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch, void *stream);
+
+/* Pre-size the internal workspace so that later device-resident calls allocate nothing. */
+int nttx_reserve(int len, int batch, int nprimes);
+
+/* Per-kernel device timing with HIP events recorded on the launch stream around every
+ * kernel of the path (no counterpart in the reference, which times the whole block with
+ * std::chrono, main.cc:283,340).  Kinds: */
+#define NTTX_K_COL_FWD 0 /* forward column pass (strided, four-step twiddle on the way out) */
+#define NTTX_K_ROW_MUL 1 /* rows: forward a, forward b, pointwise, inverse */
+#define NTTX_K_COL_INV 2 /* inverse column pass */
+#define NTTX_K_ROW_FWD 3
+#define NTTX_K_ROW_INV 4
+#define NTTX_K_SPLIT 5   /* u64 -> residues */
+#define NTTX_K_CRT 6     /* CRT recombination */
+#define NTTX_K_MISC 7
+#define NTTX_K_COUNT 8
+int nttx_profile_enable(int on);
+int nttx_profile_reset(void);
+/* Waits for the recorded events, then returns accumulated milliseconds and launch count. */
+int nttx_profile_read(int kind, double *total_ms, long long *launches);
+
+/* Decomposition chosen for a length: writes up to 3 pass sizes (log2) into logt, returns
+ * the number of passes, or a negative code. */
+int nttx_plan_info(int len, int *logt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTTX_H */

@@ -1,0 +1,205 @@
+"""ctypes binding of libnttx.so (include/nttx.h).  Mirrors the reference's call shapes:
+poly_multiply(a, b, n, p) for both harness flavours ((int,int) of monttry2.cpp:344 and
+(uint64_t,int64_t) of main.cc:78-128), ntt() for ntt_iter_barrett (main.cc:143)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnttx.so")
+
+CRT_PRIMES = (469762049, 998244353, 1004535809, 1224736769)  # main.cc:245-248
+PATH_DIRECT32, PATH_CRT4 = 0, 1
+
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+
+# every symbol include/nttx.h declares: (name, restype, argtypes)
+_SIGS = [
+    ("nttx_init", C.c_int, [C.c_int]),
+    ("nttx_shutdown", None, []),
+    ("nttx_last_error", C.c_char_p, []),
+    ("nttx_path_for", C.c_int, [C.c_uint64, C.c_int]),
+    ("nttx_poly_multiply_i32", C.c_int, [_i32p, _i32p, _i32p, C.c_int, C.c_int32]),
+    ("nttx_poly_multiply_u64", C.c_int, [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]),
+    ("nttx_poly_multiply_crt_u64", C.c_int, [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]),
+    ("nttx_poly_multiply_batch_u32", C.c_int, [_u32p, _u32p, _u32p, C.c_int, C.c_uint32, C.c_int]),
+    ("nttx_ntt_u32", C.c_int, [_u32p, C.c_int, C.c_uint32, C.c_int]),
+    ("nttx_cyclic_multiply_u32", C.c_int, [_u32p, _u32p, _u32p, C.c_int, C.c_uint32]),
+    ("nttx_crt_combine_u64", C.c_int, [C.POINTER(_u32p), _u64p, C.c_int, C.c_int, C.c_uint64]),
+    ("nttx_dev_cyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
+    ("nttx_dev_crt_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
+    ("nttx_dev_ntt_u32", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("nttx_reserve", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("nttx_profile_enable", C.c_int, [C.c_int]),
+    ("nttx_profile_reset", C.c_int, []),
+    ("nttx_profile_read", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    ("nttx_plan_info", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+]
+
+
+class NttxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nttx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def exported_symbols():
+    return [s[0] for s in _SIGS]
+
+
+def lib():
+    """Load libnttx.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if os.environ.get("NTTX_NO_TORCH") != "1":
+            # One HIP runtime per process: PyTorch's wheel carries its own libamdhip64.so.7.
+            # Loading it first makes libnttx.so bind to that same runtime instead of a second copy.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        if not os.path.exists(LIB_PATH):
+            raise NttxError(-100, f"{LIB_PATH} is missing: run `make -C ntt_amd/csrc` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in _SIGS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise NttxError(rc, lib().nttx_last_error().decode())
+    return rc
+
+
+def init(device: int = 0):
+    _check(lib().nttx_init(device))
+
+
+def shutdown():
+    if _lib is not None:
+        _lib.nttx_shutdown()
+
+
+def path_for(p: int, n: int) -> int:
+    return _check(lib().nttx_path_for(p, n))
+
+
+def plan_info(length: int):
+    lt = (C.c_int * 3)()
+    k = _check(lib().nttx_plan_info(length, lt))
+    return list(lt[:k])
+
+
+def reserve(length: int, batch: int, nprimes: int = 1):
+    _check(lib().nttx_reserve(length, batch, nprimes))
+
+
+def _arr(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+def poly_multiply(a, b, n: int, p: int, dtype=None):
+    """ab[0..2n-2] = a*b mod p.  dtype int32 -> the (int,int) harness flavour, uint64 -> the
+    (uint64_t,int64_t) flavour; default: int32 if p < 2^31 else uint64."""
+    if dtype is None:
+        dtype = np.int32 if p < (1 << 31) else np.uint64
+    dtype = np.dtype(dtype)
+    L = lib()
+    if dtype == np.int32:
+        a, b = _arr(a, np.int32)[:n], _arr(b, np.int32)[:n]
+        ab = np.zeros(max(2 * n - 1, 0), dtype=np.int32)
+        _check(L.nttx_poly_multiply_i32(a.ctypes.data_as(_i32p), b.ctypes.data_as(_i32p), ab.ctypes.data_as(_i32p), n, p))
+    elif dtype == np.uint64:
+        a, b = _arr(a, np.uint64)[:n], _arr(b, np.uint64)[:n]
+        ab = np.zeros(max(2 * n - 1, 0), dtype=np.uint64)
+        _check(L.nttx_poly_multiply_u64(a.ctypes.data_as(_u64p), b.ctypes.data_as(_u64p), ab.ctypes.data_as(_u64p), n, p))
+    else:
+        raise TypeError("dtype must be int32 or uint64")
+    return ab
+
+
+def poly_multiply_crt(a, b, n: int, p: int):
+    """Force the 4-prime CRT path (main.cc:286-338)."""
+    a, b = _arr(a, np.uint64)[:n], _arr(b, np.uint64)[:n]
+    ab = np.zeros(max(2 * n - 1, 0), dtype=np.uint64)
+    _check(lib().nttx_poly_multiply_crt_u64(a.ctypes.data_as(_u64p), b.ctypes.data_as(_u64p), ab.ctypes.data_as(_u64p), n, p))
+    return ab
+
+
+def poly_multiply_batch(a, b, p: int):
+    """a, b: [batch][n] uint32 -> [batch][2n-1]."""
+    a, b = _arr(a, np.uint32), _arr(b, np.uint32)
+    batch, n = a.shape
+    ab = np.zeros((batch, 2 * n - 1), dtype=np.uint32)
+    _check(lib().nttx_poly_multiply_batch_u32(a.ctypes.data_as(_u32p), b.ctypes.data_as(_u32p), ab.ctypes.data_as(_u32p), n, p, batch))
+    return ab
+
+
+def ntt(x, p: int, invert: bool = False):
+    """Natural-order transform of ntt_iter_barrett (main.cc:143-182), root 3, no 1/n."""
+    v = _arr(x, np.uint32).copy()
+    _check(lib().nttx_ntt_u32(v.ctypes.data_as(_u32p), len(v), p, int(bool(invert))))
+    return v
+
+
+def cyclic_multiply(a, b, p: int):
+    """ntt_compute_omp (main.cc:185-209): cyclic product of two length-2^k residue vectors."""
+    a, b = _arr(a, np.uint32), _arr(b, np.uint32)
+    c = np.empty_like(a)
+    _check(lib().nttx_cyclic_multiply_u32(a.ctypes.data_as(_u32p), b.ctypes.data_as(_u32p), c.ctypes.data_as(_u32p), len(a), p))
+    return c
+
+
+def crt_combine(residues, nout: int, p: int):
+    """CRT recombination of the four residue vectors (main.cc:313-338)."""
+    vs = [_arr(r, np.uint32) for r in residues]
+    arr = (_u32p * 4)(*[v.ctypes.data_as(_u32p) for v in vs])
+    out = np.zeros(nout, dtype=np.uint64)
+    _check(lib().nttx_crt_combine_u64(arr, out.ctypes.data_as(_u64p), len(vs[0]), nout, p))
+    return out
+
+
+# ---- device-resident calls: arguments are raw device pointers (e.g. torch tensor.data_ptr()) ----
+def dev_cyclic_multiply_u32(d_a: int, d_b: int, d_c: int, length: int, p: int, batch: int, stream: int = 0):
+    _check(lib().nttx_dev_cyclic_multiply_u32(d_a, d_b, d_c, length, p, batch, stream))
+
+
+def dev_crt_multiply_u64(d_a: int, d_b: int, d_ab: int, n: int, p: int, batch: int, stream: int = 0):
+    _check(lib().nttx_dev_crt_multiply_u64(d_a, d_b, d_ab, n, p, batch, stream))
+
+
+def dev_ntt_u32(d_x: int, length: int, p: int, invert: bool, bit_reversed_out: bool, batch: int, stream: int = 0):
+    _check(lib().nttx_dev_ntt_u32(d_x, length, p, int(bool(invert)), int(bool(bit_reversed_out)), batch, stream))
+
+
+KERNEL_KINDS = ("col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv", "split", "crt", "misc")
+
+
+def profile_enable(on: bool = True):
+    _check(lib().nttx_profile_enable(int(bool(on))))
+
+
+def profile_reset():
+    _check(lib().nttx_profile_reset())
+
+
+def profile_read():
+    """{kind: (total_ms, launches)} of the kernels timed since the last reset."""
+    out = {}
+    for k, name in enumerate(KERNEL_KINDS):
+        ms, cnt = C.c_double(0), C.c_longlong(0)
+        _check(lib().nttx_profile_read(k, C.byref(ms), C.byref(cnt)))
+        out[name] = (ms.value, cnt.value)
+    return out

@@ -1,0 +1,690 @@
+// libnttx.so: host-side plans, workspace and the C ABI (include/nttx.h) over the
+// gfx950 kernels of nttx_kernels.hpp.
+//
+// What the host side replaces in the reference: the per-call orchestration of
+// main.cc:283-341 (allocate, residue split, four single-prime products, CRT) and of
+// monttry2.cpp:375-393 (single-prime product), plus the once-per-process constants of
+// main.cc:245-270.  Twiddles, which the reference regenerates inside every butterfly
+// block by a serial w *= wn chain (main.cc:156-178), live in a plan cache keyed by
+// (p, length) and are built once.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/nttx.h"
+#include "nttx_arith.hpp"
+#include "nttx_kernels.hpp"
+
+namespace nttx {
+
+// The reference's CRT primes (main.cc:245-248); all have 3 as a quadratic non-residue and
+// 2^21 | p-1, so four-prime products support lengths up to 2^21.
+static const uint32_t kCrtPrimes[4] = {469762049u, 998244353u, 1004535809u, 1224736769u};
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+  return fail(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// ---- grow-only device buffer ----------------------------------------------------------
+struct DevBuf {
+  void *ptr = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (ptr) { HIPCHK(hipFree(ptr)); ptr = nullptr; cap = 0; }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc(&ptr, want));
+    cap = want;
+    return 0;
+  }
+  void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+// ---- plan: decomposition + device tables for one (p, log2 length, root direction) -----
+struct Plan {
+  uint32_t p = 0; int logL = 0; bool conj = false; bool lazy = false;
+  PrimeCtx ctx{};
+  int npass = 0; int lt[3] = {0, 0, 0};     // lt[0..npass-2] column passes, lt[npass-1] the row pass
+  uint32_t *tw_fwd[3] = {nullptr, nullptr, nullptr};  // stage-major tables per pass, root w
+  uint32_t *tw_inv[3] = {nullptr, nullptr, nullptr};  // same for w^{-1}
+  uint32_t *fs_fwd[2] = {nullptr, nullptr};           // four-step tables per column pass
+  uint32_t *fs_inv[2] = {nullptr, nullptr};           // inverse; level 0 also carries n^{-1} R
+  uint32_t scale_single = 0;                          // n^{-1} R^2 mod p (single-pass products)
+  ~Plan() {
+    for (auto q : tw_fwd) if (q) (void)hipFree(q);
+    for (auto q : tw_inv) if (q) (void)hipFree(q);
+    for (auto q : fs_fwd) if (q) (void)hipFree(q);
+    for (auto q : fs_inv) if (q) (void)hipFree(q);
+  }
+};
+
+constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
+
+static int decompose(int k, int lt[3]) {
+  if (k <= kMaxRowLog) { lt[0] = k; return 1; }
+  if (k <= kMaxColLog + kMaxRowLog) { lt[0] = k / 2; lt[1] = k - lt[0]; return 2; }
+  int row = (k + 2) / 3; if (row > kMaxRowLog) row = kMaxRowLog;
+  int rem = k - row;
+  lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
+  return 3;
+}
+
+// per-kernel timing with HIP events on the launch stream (bench.py's roofline figure)
+enum ProfKind { PK_COL_FWD = 0, PK_ROW_MUL, PK_COL_INV, PK_ROW_FWD, PK_ROW_INV, PK_SPLIT, PK_CRT, PK_MISC, PK_COUNT };
+struct ProfRec { hipEvent_t e0, e1; int kind; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[PK_COUNT] = {0};
+  long long launches[PK_COUNT] = {0};
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+  }
+  void begin(int kind, hipStream_t st) {
+    if (!on) return;
+    ProfRec r{get(), get(), kind};
+    (void)hipEventRecord(r.e0, st);
+    pending.push_back(r);
+  }
+  void end(hipStream_t st) { if (on && !pending.empty()) (void)hipEventRecord(pending.back().e1, st); }
+  void fold() {
+    for (auto &r : pending) {
+      (void)hipEventSynchronize(r.e1);
+      float t = 0; if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms[r.kind] += t; launches[r.kind] += 1; }
+      pool.push_back(r.e0); pool.push_back(r.e1);
+    }
+    pending.clear();
+  }
+  void reset() { fold(); for (int i = 0; i < PK_COUNT; ++i) { ms[i] = 0; launches[i] = 0; } }
+  void destroy() { fold(); for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
+};
+
+struct Context {
+  int device = -1;
+  Profiler prof;
+  std::mutex mu;
+  std::map<std::tuple<uint32_t, int, bool>, std::unique_ptr<Plan>> plans;
+  // workspace
+  DevBuf wa, wb;            // transformed copies of a and b (multi-pass direct path) [batch][len]
+  DevBuf in_a, in_b;        // raw host inputs staged on device
+  DevBuf pa, pb, pc;        // padded residues / product [nprimes][batch][len]
+  DevBuf outb;              // compacted output staged for the copy back
+  DevBuf tmp;               // transform API scratch
+};
+static Context *g_ctx = nullptr;
+static std::mutex g_init_mu;
+
+// smallest quadratic non-residue, preferring the reference's root 3 (main.cc:241)
+static uint32_t find_nonresidue(uint32_t p) {
+  const uint32_t cand[] = {3, 2, 5, 6, 7, 10, 11, 13, 14, 15, 17, 19, 21, 22, 23, 26, 29, 31, 37, 41, 43, 47};
+  for (uint32_t g : cand) if (g % p && h_powmod(g, (p - 1) / 2, p) == p - 1) return g;
+  for (uint32_t g = 48; g < p && g < 100000; ++g) if (h_powmod(g, (p - 1) / 2, p) == p - 1) return g;
+  return 0;
+}
+
+static bool direct_ok(uint64_t p, int logL) {
+  if (p < 3 || p >= (1ull << 31) || (p & 1) == 0) return false;
+  if (logL > kMaxLog) return false;
+  if (((p - 1) & ((1ull << logL) - 1)) != 0) return false;
+  if (!is_prime_u64(p)) return false;
+  return find_nonresidue((uint32_t)p) != 0;
+}
+
+static int upload(uint32_t **dst, const std::vector<uint32_t> &h) {
+  HIPCHK(hipMalloc((void **)dst, h.size() * sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(*dst, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// stage-major table for a length-T transform with primitive T-th root w (ordinary form):
+// tab[h + j] = w^(j * T/(2h)) in Montgomery form, h = 1, 2, ..., T/2
+static std::vector<uint32_t> stage_table(uint32_t w, int logT, const PrimeCtx &c) {
+  const int T = 1 << logT;
+  std::vector<uint32_t> tab(std::max(T, 2), 0);
+  for (int h = 1; h < T; h <<= 1) {
+    const uint32_t step = h_powmod(w, (uint64_t)(T / (2 * h)), c.p);
+    uint32_t cur = 1;
+    for (int j = 0; j < h; ++j) { tab[h + j] = to_mont(cur, c); cur = h_mulmod(cur, step, c.p); }
+  }
+  return tab;
+}
+
+static inline uint32_t bitrev(uint32_t x, int bits) {
+  uint32_t r = 0;
+  for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+
+// four-step table for blocks of N = T*S words: tab[j*S + s] = wN^(s * bitrev_T(j)) * extra, Montgomery form
+static std::vector<uint32_t> fourstep_table(uint32_t wN, int logT, int logS, uint32_t extra, const PrimeCtx &c) {
+  const size_t T = (size_t)1 << logT, S = (size_t)1 << logS;
+  std::vector<uint32_t> tab(T * S);
+  const uint32_t e0 = to_mont(extra, c);
+  for (size_t j = 0; j < T; ++j) {
+    const uint32_t step = to_mont(h_powmod(wN, bitrev((uint32_t)j, logT), c.p), c);
+    uint32_t cur = e0;  // Montgomery form of extra * step^s
+    uint32_t *row = &tab[j * S];
+    for (size_t s = 0; s < S; ++s) { row[s] = cur; cur = mont_mul(cur, step, c.p, c.npinv); }
+  }
+  return tab;
+}
+
+static int get_plan(Context *cx, uint32_t p, int logL, bool conj, Plan **out) {
+  auto key = std::make_tuple(p, logL, conj);
+  auto it = cx->plans.find(key);
+  if (it != cx->plans.end()) { *out = it->second.get(); return 0; }
+  if (!direct_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %u does not support a direct length-2^%d transform", p, logL);
+  std::unique_ptr<Plan> pl(new Plan);
+  pl->p = p; pl->logL = logL; pl->conj = conj; pl->lazy = p < (1u << 30);
+  pl->ctx = make_ctx(p);
+  pl->npass = decompose(logL, pl->lt);
+  const uint32_t g = find_nonresidue(p);
+  uint32_t wL = h_powmod(g, (uint64_t)(p - 1) >> logL, p);        // primitive 2^logL-th root (main.cc:156)
+  if (conj) wL = h_powmod(wL, p - 2, p);                          // main.cc:157
+  const uint32_t wLi = h_powmod(wL, p - 2, p);
+  const uint64_t Lfull = 1ull << logL;
+  const uint32_t ninv = h_powmod((uint32_t)(Lfull % p), p - 2, p);  // main.cc:204
+  const uint32_t ninvR = to_mont(ninv, pl->ctx);                    // n^{-1} R mod p
+  pl->scale_single = to_mont(ninvR, pl->ctx);                       // n^{-1} R^2 mod p
+  int logN = logL;                                                  // block length handled by this level
+  for (int lv = 0; lv < pl->npass; ++lv) {
+    const int lt = pl->lt[lv];
+    const uint32_t wN = h_powmod(wL, Lfull >> logN, p), wNi = h_powmod(wLi, Lfull >> logN, p);
+    const uint32_t wT = h_powmod(wN, (1ull << logN) >> lt, p), wTi = h_powmod(wNi, (1ull << logN) >> lt, p);
+    if (int rc = upload(&pl->tw_fwd[lv], stage_table(wT, lt, pl->ctx))) return rc;
+    if (int rc = upload(&pl->tw_inv[lv], stage_table(wTi, lt, pl->ctx))) return rc;
+    if (lv < pl->npass - 1) {
+      const int logS = logN - lt;
+      if (int rc = upload(&pl->fs_fwd[lv], fourstep_table(wN, lt, logS, 1, pl->ctx))) return rc;
+      if (int rc = upload(&pl->fs_inv[lv], fourstep_table(wNi, lt, logS, lv == 0 ? ninvR : 1, pl->ctx))) return rc;
+      logN = logS;
+    }
+  }
+  *out = pl.get();
+  cx->plans[key] = std::move(pl);
+  return 0;
+}
+
+// ---- kernel dispatch -------------------------------------------------------------------
+static int grid_for(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
+
+template <int MODE, bool LAZY>
+static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
+#define NTTX_ROW_CASE(K) case K: { \
+    using Lyt = RowLayout<K>; \
+    const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
+    hipLaunchKernelGGL((row_kernel<K, MODE, LAZY>), dim3(grid_for(tiles, 8192)), dim3(WG), 0, st, A); break; }
+  switch (logT) {
+    NTTX_ROW_CASE(1) NTTX_ROW_CASE(2) NTTX_ROW_CASE(3) NTTX_ROW_CASE(4) NTTX_ROW_CASE(5) NTTX_ROW_CASE(6)
+    NTTX_ROW_CASE(7) NTTX_ROW_CASE(8) NTTX_ROW_CASE(9) NTTX_ROW_CASE(10) NTTX_ROW_CASE(11)
+    default: return fail(NTTX_ERANGE, "row pass of 2^%d points unsupported", logT);
+  }
+#undef NTTX_ROW_CASE
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_row_raw(int mode, bool lazy, int logT, const RowArgs &A, hipStream_t st) {
+  if (mode == ROW_FWD) return lazy ? launch_row_t<ROW_FWD, true>(logT, A, st) : launch_row_t<ROW_FWD, false>(logT, A, st);
+  if (mode == ROW_INV) return lazy ? launch_row_t<ROW_INV, true>(logT, A, st) : launch_row_t<ROW_INV, false>(logT, A, st);
+  return lazy ? launch_row_t<ROW_MUL, true>(logT, A, st) : launch_row_t<ROW_MUL, false>(logT, A, st);
+}
+
+template <bool INV, bool LAZY>
+static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
+  const long long tiles = A.nblocks * ((1ll << A.logS) / COLS);
+#define NTTX_COL_CASE(K) case K: \
+    hipLaunchKernelGGL((col_kernel<K, INV, LAZY>), dim3(grid_for(tiles, 4096), 1, nvec), dim3(WG), 0, st, A); break;
+  switch (logT) {
+    NTTX_COL_CASE(6) NTTX_COL_CASE(7) NTTX_COL_CASE(8) NTTX_COL_CASE(9) NTTX_COL_CASE(10)
+    default: return fail(NTTX_ERANGE, "column pass of 2^%d points unsupported", logT);
+  }
+#undef NTTX_COL_CASE
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_col_raw(bool inv, bool lazy, int logT, const ColArgs &A, int nvec, hipStream_t st) {
+  if (logT < kMinColLog || A.logS < 4) return fail(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
+  if (!inv) return lazy ? launch_col_t<false, true>(logT, A, nvec, st) : launch_col_t<false, false>(logT, A, nvec, st);
+  return lazy ? launch_col_t<true, true>(logT, A, nvec, st) : launch_col_t<true, false>(logT, A, nvec, st);
+}
+
+static int launch_row(Context *cx, int mode, bool lazy, int logT, const RowArgs &A, hipStream_t st) {
+  cx->prof.begin(mode == ROW_MUL ? PK_ROW_MUL : mode == ROW_FWD ? PK_ROW_FWD : PK_ROW_INV, st);
+  const int rc = launch_row_raw(mode, lazy, logT, A, st);
+  cx->prof.end(st);
+  return rc;
+}
+static int launch_col(Context *cx, bool inv, bool lazy, int logT, const ColArgs &A, int nvec, hipStream_t st) {
+  cx->prof.begin(inv ? PK_COL_INV : PK_COL_FWD, st);
+  const int rc = launch_col_raw(inv, lazy, logT, A, nvec, st);
+  cx->prof.end(st);
+  return rc;
+}
+
+static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 * 16); }
+
+// ---- device-resident building blocks ---------------------------------------------------
+
+// c = cyclic product of a and b, all [batch][2^logL] u32 on the device
+static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
+                               hipStream_t st) {
+  const long long len = 1ll << pl->logL;
+  if (pl->npass == 1) {
+    RowArgs R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
+    R.ctx = pl->ctx; R.scale = pl->scale_single; R.canon_out = 1; R.nrows = batch;
+    return launch_row(cx, ROW_MUL, pl->lazy, pl->lt[0], R, st);
+  }
+  if (int rc = cx->wa.ensure((size_t)batch * len * 4)) return rc;
+  if (int rc = cx->wb.ensure((size_t)batch * len * 4)) return rc;
+  uint32_t *wa = cx->wa.as<uint32_t>(), *wb = cx->wb.as<uint32_t>();
+  int logN = pl->logL;
+  const int ncol = pl->npass - 1;
+  for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
+    ColArgs C{}; C.in[0] = lv == 0 ? a : wa; C.in[1] = lv == 0 ? b : wb; C.out[0] = wa; C.out[1] = wb;
+    C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
+    C.nblocks = ((long long)batch << pl->logL) >> logN;
+    if (int rc = launch_col(cx, false, pl->lazy, pl->lt[lv], C, 2, st)) return rc;
+    logN = C.logS;
+  }
+  {                                              // rows: forward a, forward b, pointwise, inverse
+    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
+    R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
+    if (int rc = launch_row(cx, ROW_MUL, pl->lazy, pl->lt[ncol], R, st)) return rc;
+  }
+  for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
+    int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
+    ColArgs C{}; C.in[0] = c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
+    C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
+    C.nblocks = ((long long)batch << pl->logL) >> logNl;
+    if (int rc = launch_col(cx, true, pl->lazy, pl->lt[lv], C, 1, st)) return rc;
+  }
+  return 0;
+}
+
+// forward transform (root w of the plan), natural in -> bit-reversed out, in place on x
+static int dev_forward(Context *cx, Plan *pl, uint32_t *x, int batch, bool canon, hipStream_t st) {
+  int logN = pl->logL;
+  const int ncol = pl->npass - 1;
+  for (int lv = 0; lv < ncol; ++lv) {
+    ColArgs C{}; C.in[0] = x; C.out[0] = x; C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx;
+    C.logS = logN - pl->lt[lv]; C.canon_out = 0; C.nblocks = ((long long)batch << pl->logL) >> logN;
+    if (int rc = launch_col(cx, false, pl->lazy, pl->lt[lv], C, 1, st)) return rc;
+    logN = C.logS;
+  }
+  RowArgs R{}; R.in0 = x; R.out = x; R.tw_fwd = pl->tw_fwd[ncol]; R.ctx = pl->ctx; R.canon_out = canon;
+  R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
+  return launch_row(cx, ROW_FWD, pl->lazy, pl->lt[ncol], R, st);
+}
+
+// ---- CRT constants (main.cc:256-270 computes M, K_i = M/m_i, K_i^{-1} mod m_i; the Garner
+// form needs m_i^{-1} mod m_j for i < j instead) ------------------------------------------
+struct CrtConst { PrimeCtx ctx[4]; uint32_t inv[4][4]; unsigned __int128 M; };
+static const CrtConst &crt_const() {
+  static CrtConst cc = [] {
+    CrtConst c{}; c.M = 1;
+    for (int i = 0; i < 4; ++i) { c.ctx[i] = make_ctx(kCrtPrimes[i]); c.M *= kCrtPrimes[i]; }
+    for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) {
+      const uint32_t mj = kCrtPrimes[j];
+      c.inv[i][j] = to_mont(h_powmod(kCrtPrimes[i] % mj, mj - 2, mj), c.ctx[j]);
+    }
+    return c;
+  }();
+  return cc;
+}
+
+static int fill_crt_args(CrtArgs &A, uint64_t p) {
+  const CrtConst &cc = crt_const();
+  for (int k = 0; k < 4; ++k) { A.ctx[k] = cc.ctx[k]; for (int j = 0; j < 4; ++j) A.inv[k][j] = cc.inv[k][j]; }
+  A.nmod = 4;
+  if (p < 2 || p >= (1ull << 63)) return fail(NTTX_EINVAL, "modulus out of range");
+  if ((p & 1) == 0) return fail(NTTX_EINVAL, "even modulus %llu is not supported by the CRT recombination", (unsigned long long)p);
+  A.pctx = make_ctx64(p);
+  const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % p);
+  for (int k = 0; k < 4; ++k) A.mR[k] = h_mulmod64(kCrtPrimes[k] % p, R, p);
+  return 0;
+}
+
+// exactness bound of the 4-prime path: every coefficient of the integer product, at most
+// n*(amax)*(bmax) with amax,bmax <= p-1, must stay below M (cf. "sum % M" main.cc:330)
+static bool crt_bound_ok(uint64_t p, int n) {
+  const CrtConst &cc = crt_const();
+  const long double lim = (long double)cc.M;
+  const long double need = (long double)n * (long double)(p - 1) * (long double)(p - 1);
+  return need < lim * 0.999L;
+}
+
+static int log2_ceil_len(int n) {  // main.cc:278-279: smallest power of two >= 2n
+  int k = 0;
+  while ((1ll << k) < 2ll * n) ++k;
+  return k;
+}
+
+// d_ab[b][0..2n-2] from u64 device inputs through the 4-prime path
+static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_ab, int n, uint64_t p,
+                            int batch, hipStream_t st) {
+  const int logL = log2_ceil_len(n);
+  if (logL > 21) return fail(NTTX_ERANGE, "length 2^%d exceeds the CRT prime set (2^21)", logL);
+  if (!crt_bound_ok(p, n)) return fail(NTTX_ERANGE, "n*(p-1)^2 exceeds the product of the CRT primes");
+  const long long len = 1ll << logL;
+  const size_t vec = (size_t)batch * len * 4;
+  if (int rc = cx->pa.ensure(4 * vec)) return rc;
+  if (int rc = cx->pb.ensure(4 * vec)) return rc;
+  if (int rc = cx->pc.ensure(4 * vec)) return rc;
+  Plan *pl[4];
+  for (int k = 0; k < 4; ++k) if (int rc = get_plan(cx, kCrtPrimes[k], logL, false, &pl[k])) return rc;
+  for (int which = 0; which < 2; ++which) {
+    SplitArgs S{}; S.src = which ? d_b : d_a; S.nmod = 4; S.n = n; S.len = (int)len; S.total = (long long)batch * len;
+    for (int k = 0; k < 4; ++k) { S.dst[k] = (which ? cx->pb : cx->pa).as<uint32_t>() + (size_t)k * batch * len; S.mod[k] = kCrtPrimes[k]; }
+    cx->prof.begin(PK_SPLIT, st);
+    hipLaunchKernelGGL(split_kernel, dim3(ew_grid(S.total)), dim3(256), 0, st, S);
+    cx->prof.end(st);
+    HIPCHK(hipGetLastError());
+  }
+  CrtArgs A{};
+  if (int rc = fill_crt_args(A, p)) return rc;
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t *a = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
+    const uint32_t *b = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
+    uint32_t *c = cx->pc.as<uint32_t>() + (size_t)k * batch * len;
+    if (int rc = dev_cyclic_multiply(cx, pl[k], a, b, c, batch, st)) return rc;
+    A.res[k] = c;
+  }
+  A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len; A.total = (long long)batch * A.nout;
+  cx->prof.begin(PK_CRT, st);
+  hipLaunchKernelGGL(crt_kernel, dim3(ew_grid(A.total)), dim3(256), 0, st, A);
+  cx->prof.end(st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace nttx
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+using namespace nttx;
+
+#define NTTX_ENTER() \
+  if (!g_ctx) return fail(NTTX_ENOINIT, "nttx_init has not been called"); \
+  Context *cx = g_ctx; std::lock_guard<std::mutex> lock_(cx->mu); \
+  HIPCHK(hipSetDevice(cx->device));
+
+extern "C" {
+
+const char *nttx_last_error(void) { return g_err.c_str(); }
+
+int nttx_init(int device) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(NTTX_EDEVICE, "no HIP device available: %s", hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(NTTX_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
+  if (g_ctx && g_ctx->device == device) return 0;
+  if (g_ctx) return fail(NTTX_EINVAL, "already initialised on device %d; call nttx_shutdown first", g_ctx->device);
+  HIPCHK(hipSetDevice(device));
+  g_ctx = new Context;
+  g_ctx->device = device;
+  (void)crt_const();
+  return 0;
+}
+
+void nttx_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_ctx) return;
+  (void)hipSetDevice(g_ctx->device);
+  (void)hipDeviceSynchronize();
+  g_ctx->plans.clear();
+  g_ctx->prof.destroy();
+  for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
+    b->release();
+  delete g_ctx;
+  g_ctx = nullptr;
+}
+
+int nttx_path_for(uint64_t p, int n) {
+  if (n <= 0 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
+  return direct_ok(p, log2_ceil_len(n)) ? NTTX_PATH_DIRECT32 : NTTX_PATH_CRT4;
+}
+
+int nttx_plan_info(int len, int *logt) {
+  if (len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two >= 2");
+  int k = 0; while ((1 << k) < len) ++k;
+  int lt[3] = {0, 0, 0};
+  const int np = decompose(k, lt);
+  if (logt) for (int i = 0; i < np; ++i) logt[i] = lt[i];
+  return np;
+}
+
+int nttx_profile_enable(int on) {
+  NTTX_ENTER();
+  cx->prof.fold();
+  cx->prof.on = on != 0;
+  return 0;
+}
+
+int nttx_profile_reset(void) {
+  NTTX_ENTER();
+  cx->prof.reset();
+  return 0;
+}
+
+int nttx_profile_read(int kind, double *total_ms, long long *launches) {
+  NTTX_ENTER();
+  if (kind < 0 || kind >= PK_COUNT) return fail(NTTX_EINVAL, "kernel kind out of range");
+  cx->prof.fold();
+  if (total_ms) *total_ms = cx->prof.ms[kind];
+  if (launches) *launches = cx->prof.launches[kind];
+  return 0;
+}
+
+int nttx_reserve(int len, int batch, int nprimes) {
+  NTTX_ENTER();
+  if (len < 2 || batch < 1 || nprimes < 1 || nprimes > 4) return fail(NTTX_EINVAL, "bad arguments");
+  const size_t vec = (size_t)batch * len * 4;
+  if (int rc = cx->wa.ensure(vec)) return rc;
+  if (int rc = cx->wb.ensure(vec)) return rc;
+  if (nprimes > 1) {
+    if (int rc = cx->pa.ensure(nprimes * vec)) return rc;
+    if (int rc = cx->pb.ensure(nprimes * vec)) return rc;
+    if (int rc = cx->pc.ensure(nprimes * vec)) return rc;
+  }
+  return 0;
+}
+
+int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_c || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
+  int k = 0; while ((1ll << k) < len) ++k;
+  Plan *pl;
+  if (int rc = get_plan(cx, p, k, false, &pl)) return rc;
+  return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch, (hipStream_t)stream);
+}
+
+int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_ab || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
+  return dev_crt_multiply(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint64_t *)d_ab, n, p, batch, (hipStream_t)stream);
+}
+
+static int dev_ntt_impl(Context *cx, uint32_t *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch,
+                        hipStream_t st) {
+  if (len == 1) return 0;
+  int k = 0; while ((1ll << k) < len) ++k;
+  Plan *pl;
+  if (int rc = get_plan(cx, p, k, inverse != 0, &pl)) return rc;
+  if (int rc = dev_forward(cx, pl, d_x, batch, true, st)) return rc;
+  if (!bit_reversed_out) {
+    const long long total = (long long)batch * len;
+    if (int rc = cx->tmp.ensure((size_t)total * 4)) return rc;
+    HIPCHK(hipMemcpyAsync(cx->tmp.ptr, d_x, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(bitrev_kernel, dim3(ew_grid(total)), dim3(256), 0, st, cx->tmp.as<uint32_t>(), d_x, k, total);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int nttx_dev_ntt_u32(void *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_x || batch < 1 || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
+  return dev_ntt_impl(cx, (uint32_t *)d_x, len, p, inverse, bit_reversed_out, batch, (hipStream_t)stream);
+}
+
+int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse) {
+  NTTX_ENTER();
+  if (!x || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two");
+  if (int rc = cx->in_a.ensure((size_t)len * 4)) return rc;
+  HIPCHK(hipMemcpy(cx->in_a.ptr, x, (size_t)len * 4, hipMemcpyHostToDevice));
+  if (int rc = dev_ntt_impl(cx, cx->in_a.as<uint32_t>(), len, p, inverse, 0, 1, nullptr)) return rc;
+  HIPCHK(hipMemcpy(x, cx->in_a.ptr, (size_t)len * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, int len, uint32_t p) {
+  NTTX_ENTER();
+  if (!a || !b || !c || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
+  int k = 0; while ((1ll << k) < len) ++k;
+  Plan *pl;
+  if (int rc = get_plan(cx, p, k, false, &pl)) return rc;
+  const size_t bytes = (size_t)len * 4;
+  if (int rc = cx->pa.ensure(bytes)) return rc;
+  if (int rc = cx->pb.ensure(bytes)) return rc;
+  if (int rc = cx->pc.ensure(bytes)) return rc;
+  HIPCHK(hipMemcpy(cx->pa.ptr, a, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cx->pb.ptr, b, bytes, hipMemcpyHostToDevice));
+  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr)) return rc;
+  HIPCHK(hipMemcpy(c, cx->pc.ptr, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, int nout, uint64_t p) {
+  NTTX_ENTER();
+  if (!res || !ab || len < 1 || nout < 1 || nout > len) return fail(NTTX_EINVAL, "bad arguments");
+  const size_t bytes = (size_t)len * 4;
+  if (int rc = cx->pc.ensure(4 * bytes)) return rc;
+  if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
+  CrtArgs A{};
+  if (int rc = fill_crt_args(A, p)) return rc;
+  for (int k = 0; k < 4; ++k) {
+    if (!res[k]) return fail(NTTX_EINVAL, "null residue vector");
+    uint32_t *d = cx->pc.as<uint32_t>() + (size_t)k * len;
+    HIPCHK(hipMemcpy(d, res[k], bytes, hipMemcpyHostToDevice));
+    A.res[k] = d;
+  }
+  A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len; A.total = nout;
+  hipLaunchKernelGGL(crt_kernel, dim3(ew_grid(A.total)), dim3(256), 0, 0, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// shared body of the host-buffer direct path: raw u32 coefficients [batch][n] -> [batch][2n-1]
+static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch) {
+  const int logL = log2_ceil_len(n);
+  Plan *pl;
+  if (int rc = get_plan(cx, p, logL, false, &pl)) return rc;
+  const long long len = 1ll << logL;
+  const size_t raw = (size_t)batch * n * 4, vec = (size_t)batch * len * 4;
+  const int nout = 2 * n - 1;
+  if (int rc = cx->in_a.ensure(raw)) return rc;
+  if (int rc = cx->in_b.ensure(raw)) return rc;
+  if (int rc = cx->pa.ensure(vec)) return rc;
+  if (int rc = cx->pb.ensure(vec)) return rc;
+  if (int rc = cx->pc.ensure(vec)) return rc;
+  if (int rc = cx->outb.ensure((size_t)batch * nout * 4)) return rc;
+  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  const long long total = (long long)batch * len;
+  hipLaunchKernelGGL(pad_kernel, dim3(ew_grid(total)), dim3(256), 0, 0, cx->in_a.as<uint32_t>(), cx->pa.as<uint32_t>(), p, n, (int)len, total);
+  hipLaunchKernelGGL(pad_kernel, dim3(ew_grid(total)), dim3(256), 0, 0, cx->in_b.as<uint32_t>(), cx->pb.as<uint32_t>(), p, n, (int)len, total);
+  HIPCHK(hipGetLastError());
+  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), batch, nullptr)) return rc;
+  const long long tout = (long long)batch * nout;
+  hipLaunchKernelGGL((unpad_kernel<uint32_t>), dim3(ew_grid(tout)), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len, tout);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)tout * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nttx_poly_multiply_batch_u32(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch) {
+  NTTX_ENTER();
+  if (!a || !b || !ab || n < 1 || batch < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
+  if (!direct_ok(p, log2_ceil_len(n))) return fail(NTTX_EINVAL, "modulus %u has no direct transform of this length; use the u64 entry point", p);
+  return host_direct_u32(cx, a, b, ab, n, p, batch);
+}
+
+int nttx_poly_multiply_i32(const int32_t *a, const int32_t *b, int32_t *ab, int n, int32_t p) {
+  if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
+  if (nttx_path_for((uint64_t)p, n) == NTTX_PATH_DIRECT32) {
+    NTTX_ENTER();
+    return host_direct_u32(cx, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)ab, n, (uint32_t)p, 1);
+  }
+  std::vector<uint64_t> wa(n), wb(n), wc(2 * (size_t)n - 1);
+  for (int i = 0; i < n; ++i) { wa[i] = (uint32_t)a[i]; wb[i] = (uint32_t)b[i]; }
+  if (int rc = nttx_poly_multiply_crt_u64(wa.data(), wb.data(), wc.data(), n, (uint64_t)p)) return rc;
+  for (size_t i = 0; i < wc.size(); ++i) ab[i] = (int32_t)wc[i];
+  return 0;
+}
+
+int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
+  NTTX_ENTER();
+  if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
+  const size_t raw = (size_t)n * 8, nout = 2 * (size_t)n - 1;
+  if (int rc = cx->in_a.ensure(raw)) return rc;
+  if (int rc = cx->in_b.ensure(raw)) return rc;
+  if (int rc = cx->outb.ensure(nout * 8)) return rc;
+  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  if (int rc = dev_crt_multiply(cx, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->outb.as<uint64_t>(), n, p, 1, nullptr)) return rc;
+  HIPCHK(hipMemcpy(ab, cx->outb.ptr, nout * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
+  if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
+  if (nttx_path_for(p, n) != NTTX_PATH_DIRECT32) return nttx_poly_multiply_crt_u64(a, b, ab, n, p);
+  NTTX_ENTER();
+  // direct path on 32-bit lanes: reduce the u64 coefficients mod p on the device (one modulus)
+  const int logL = log2_ceil_len(n);
+  Plan *pl;
+  if (int rc = get_plan(cx, (uint32_t)p, logL, false, &pl)) return rc;
+  const long long len = 1ll << logL;
+  const size_t raw = (size_t)n * 8, vec = (size_t)len * 4;
+  const int nout = 2 * n - 1;
+  if (int rc = cx->in_a.ensure(raw)) return rc;
+  if (int rc = cx->in_b.ensure(raw)) return rc;
+  if (int rc = cx->pa.ensure(vec)) return rc;
+  if (int rc = cx->pb.ensure(vec)) return rc;
+  if (int rc = cx->pc.ensure(vec)) return rc;
+  if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
+  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  for (int which = 0; which < 2; ++which) {
+    SplitArgs S{}; S.src = (which ? cx->in_b : cx->in_a).as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len; S.total = len;
+    S.dst[0] = (which ? cx->pb : cx->pa).as<uint32_t>(); S.mod[0] = (uint32_t)p;
+    hipLaunchKernelGGL(split_kernel, dim3(ew_grid(S.total)), dim3(256), 0, 0, S);
+  }
+  HIPCHK(hipGetLastError());
+  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr)) return rc;
+  hipLaunchKernelGGL((unpad_kernel<uint64_t>), dim3(ew_grid(nout)), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len, (long long)nout);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"
