@@ -1,0 +1,115 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the
+header declares, host-side dispatch logic, the harness file formats, batch sharding."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nttx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nttx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ntt_amd
+    L = ntt_amd.lib()
+    names = declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(ntt_amd.exported_symbols()) == names
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a device the product must fail loudly, never compute on the host."""
+    import torch
+    import ntt_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ntt_amd.NttxError) as e:
+        ntt_amd.init(0)
+    assert e.value.code == -3
+    with pytest.raises(ntt_amd.NttxError) as e:
+        ntt_amd.poly_multiply([1, 2], [3, 4], 2, 7340033)
+    assert e.value.code == -4
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ntt_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().lower(), f
+
+
+def test_path_selection():
+    import ntt_amd
+    D, C = ntt_amd.PATH_DIRECT32, ntt_amd.PATH_CRT4
+    assert ntt_amd.path_for(7340033, 4) == D
+    assert ntt_amd.path_for(7340033, 131072) == D           # 2^18 | 7 * 2^20
+    assert ntt_amd.path_for(7340033, 1 << 20) == C          # would need 2^21
+    assert ntt_amd.path_for(104857601, 131072) == D
+    assert ntt_amd.path_for(469762049, 131072) == D
+    assert ntt_amd.path_for(1224736769, 131072) == D        # > 2^30: canonical-lane kernels
+    assert ntt_amd.path_for(1337006139375617, 131072) == C  # 51-bit modulus (test.o:11)
+    assert ntt_amd.path_for(1000000007, 8) == C             # prime but 2^4 does not divide p-1
+    assert ntt_amd.path_for(7340033 * 3, 4) == C            # composite
+
+
+def test_plan_decomposition():
+    import ntt_amd
+    assert ntt_amd.plan_info(2) == [1]
+    assert ntt_amd.plan_info(1 << 11) == [11]
+    assert ntt_amd.plan_info(1 << 12) == [6, 6]
+    assert ntt_amd.plan_info(1 << 18) == [9, 9]
+    assert ntt_amd.plan_info(1 << 21) == [10, 11]
+    for k in range(22, 31):
+        lt = ntt_amd.plan_info(1 << k)
+        assert len(lt) == 3 and sum(lt) == k and all(6 <= x <= 10 for x in lt[:2]) and lt[2] <= 11
+    with pytest.raises(ntt_amd.NttxError):
+        ntt_amd.plan_info(12)
+
+
+def test_harness_file_formats(tmp_path, oracle):
+    """fRead / fWrite / fCheck keep the reference's formats (main.cc:78-128)."""
+    from ntt_amd import harness
+    from oracle import pyoracle as po
+    p, n = 104857601, 37
+    a, b = oracle.fill_random(n, 5, p), oracle.fill_random(n, 6, p)
+    d = tmp_path / "nttdata"
+    d.mkdir()
+    po.write_in_file(str(d / "7.in"), a, b, p)
+    ra, rb, rn, rp = harness.fRead(7, str(d))
+    assert rn == n and rp == p and np.array_equal(ra, a) and np.array_equal(rb, b)
+    ab = oracle.poly_multiply_crt(a, b, p)
+    harness.fWrite(ab, n, 7, str(d / "files"))
+    text = open(d / "files" / "7.out").read()
+    assert text == "".join(f"{int(x)}\n" for x in ab)
+    os.rename(d / "files" / "7.out", d / "7.out")
+    assert harness.fCheck(ab, n, 7, str(d), quiet=True)
+    bad = ab.copy()
+    bad[3] ^= 1
+    assert not harness.fCheck(bad, n, 7, str(d), quiet=True)
+    # the golden id0 pair round-trips through the same reader
+    gold = os.path.join(ROOT, "tests", "golden")
+    a0, b0, n0, p0 = harness.fRead(0, gold)
+    assert (list(a0), list(b0), n0, p0) == ([1, 5, 5, 4], [4, 1, 5, 2], 4, 7340033)
+    assert harness.fCheck(oracle.poly_multiply_crt(a0, b0, p0), n0, 0, gold, quiet=True)
+
+
+def test_shard_range():
+    from ntt_amd.sharding import prime_owner, shard_range
+    for total in (0, 1, 7, 256, 4096):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_range(total, r, world)
+                cover += list(range(lo, hi))
+                assert 0 <= hi - lo <= total // world + 1
+            assert cover == list(range(total))
+    assert [prime_owner(k, 4) for k in range(4)] == [0, 1, 2, 3]
+    assert [prime_owner(k, 2) for k in range(4)] == [0, 1, 0, 1]

@@ -1,6 +1,7 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Integer work: the bar is bit-exact equality."""
 import hashlib
+import json
 import os
 
 import numpy as np
@@ -88,10 +89,8 @@ def test_harness_sizes_full(nttx, oracle, tid):
     assert np.array_equal(got, want)
     # the forced CRT path (what main.cc runs for every id) gives the same coefficients
     assert np.array_equal(nttx.poly_multiply_crt(a, b, n, p), want)
-    gold = os.path.join(GOLD, "harness_sha256.txt")
-    if os.path.exists(gold):
-        lines = dict(l.split() for l in open(gold).read().splitlines() if l.strip())
-        assert hashlib.sha256(got.astype("<u8").tobytes()).hexdigest() == lines[str(tid)]
+    c = json.load(open(os.path.join(GOLD, "harness.json")))["cases"][f"{tid}_17"]
+    assert hashlib.sha256(got.astype("<u8").tobytes()).hexdigest() == c["sha256"]
 
 
 def test_batch(nttx, oracle):
@@ -159,3 +158,102 @@ def test_device_resident_api(nttx, oracle):
     assert np.array_equal(da.cpu().numpy().view(np.uint32), a)
     for i in range(batch):
         assert np.array_equal(c[i], oracle.ntt_compute(a[i], b[i], p)), i
+
+
+def _seeds(n, p):
+    return (n * 1000003 + p) % (1 << 62), (n * 999983 + 7 * p + 1) % (1 << 62)
+
+
+def test_golden_small_products(nttx, oracle):
+    """Outputs of the real reference programs (tests/golden/small_products.npz)."""
+    z = np.load(os.path.join(GOLD, "small_products.npz"))
+    for key in z.files:
+        kind, p, n = key.split("_")
+        p, n = int(p), int(n)
+        sa, sb = _seeds(n, p)
+        a, b = oracle.fill_random(n, sa, p), oracle.fill_random(n, sb, p)
+        if kind == "main":
+            assert np.array_equal(nttx.poly_multiply(a, b, n, p, dtype=np.uint64), z[key]), key
+            assert np.array_equal(nttx.poly_multiply_crt(a, b, n, p), z[key]), key
+        else:
+            got = nttx.poly_multiply(a.astype(np.int32), b.astype(np.int32), n, p, dtype=np.int32)
+            assert np.array_equal(got.astype(np.uint32), z[key]), key
+
+
+def test_golden_transforms(nttx, oracle):
+    z = np.load(os.path.join(GOLD, "transforms.npz"))
+    for key in z.files:
+        d, p, logn = key.split("_")
+        p, logn = int(p), int(logn)
+        x = oracle.fill_random(1 << logn, 424242 + logn + p % 1000, p).astype(np.uint32)
+        assert np.array_equal(nttx.ntt(x, p, d == "inv"), z[key]), key
+
+
+@pytest.mark.parametrize("logn", (15, 16))
+def test_golden_harness_hashes(nttx, oracle, logn):
+    h = json.load(open(os.path.join(GOLD, "harness.json")))
+    for tid in (1, 2, 3, 4):
+        c = h["cases"][f"{tid}_{logn}"]
+        a = oracle.fill_random(c["n"], 1000 + tid + 10 * logn, c["p"])
+        b = oracle.fill_random(c["n"], 2000 + tid + 10 * logn, c["p"])
+        got = nttx.poly_multiply(a, b, c["n"], c["p"], dtype=np.uint64)
+        assert hashlib.sha256(got.astype("<u8").tobytes()).hexdigest() == c["sha256"]
+
+
+def test_linearity_and_roundtrip_large(nttx, oracle):
+    """Size-independent properties at 2^20 points: forward then inverse transform is n*x, and
+    the product is bilinear."""
+    p, L = 998244353, 1 << 20
+    x = oracle.fill_random(L, 5, p).astype(np.uint32)
+    y = nttx.ntt(nttx.ntt(x, p, False), p, True)
+    assert np.array_equal(y.astype(np.uint64), x.astype(np.uint64) * (L % p) % p)
+    n = L // 2
+    a, b, c = (oracle.fill_random(n, s, p) for s in (6, 7, 8))
+    ab = nttx.poly_multiply(a, b, n, p, dtype=np.uint64)
+    ac = nttx.poly_multiply(a, c, n, p, dtype=np.uint64)
+    a_bc = nttx.poly_multiply(a, (b + c) % p, n, p, dtype=np.uint64)
+    assert np.array_equal(a_bc, (ab + ac) % p)
+
+
+def test_harness_flow(nttx, oracle, tmp_path):
+    """fRead -> poly_multiply -> fCheck -> fWrite over ids 0..4 with the reference's file formats."""
+    from oracle import pyoracle as po
+    from ntt_amd import harness
+    d = tmp_path / "nttdata"
+    d.mkdir()
+    cases = [([1, 5, 5, 4], [4, 1, 5, 2], 7340033)]
+    for tid in (1, 2, 3, 4):
+        p = P_ID[tid]
+        cases.append((rand(oracle, 4096, 1 + tid, p), rand(oracle, 4096, 9 + tid, p), p))
+    for i, (a, b, p) in enumerate(cases):
+        po.write_in_file(str(d / f"{i}.in"), a, b, p)
+        po.write_out_file(str(d / f"{i}.out"), oracle.poly_multiply_crt(a, b, p))
+    assert harness.run(0, 4, str(d), str(tmp_path / "files"))
+    assert open(tmp_path / "files" / "0.out").read() == open(os.path.join(GOLD, "0.out")).read()
+
+
+def test_cpp_harness_binary(oracle, tmp_path):
+    """nttx_harness (C++ driver over the C ABI) on ids 0..4: stdout lines and dumps as the reference's."""
+    import subprocess
+    from oracle import pyoracle as po
+    exe = os.path.join(os.path.dirname(GOLD), "..", "ntt_amd", "csrc", "nttx_harness")
+    d = tmp_path / "nttdata"
+    d.mkdir()
+    (tmp_path / "files").mkdir()
+    cases = [([1, 5, 5, 4], [4, 1, 5, 2], 7340033)]
+    for tid in (1, 2, 3, 4):
+        p = P_ID[tid]
+        cases.append((rand(oracle, 131072, 1000 + tid, p), rand(oracle, 131072, 2000 + tid, p), p))
+    wants = []
+    for i, (a, b, p) in enumerate(cases):
+        po.write_in_file(str(d / f"{i}.in"), a, b, p)
+        wants.append(oracle.poly_multiply_crt(a, b, p))
+        po.write_out_file(str(d / f"{i}.out"), wants[-1])
+    env = dict(os.environ, NTT_DATA_DIR=str(d), NTT_OUT_DIR=str(tmp_path / "files"))
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("多项式乘法结果正确") == 5
+    assert r.stdout.count("average latency for n = 131072") == 4
+    for i in range(5):
+        got = np.loadtxt(tmp_path / "files" / f"{i}.out", dtype=np.uint64, ndmin=1)
+        assert np.array_equal(got, wants[i])
