@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="multiplications per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-check", action="store_true", help="ablation builds only: skip the oracle spot-check")
     args = ap.parse_args()
 
     import numpy as np
@@ -104,7 +105,7 @@ def main():
     torch.cuda.synchronize()
 
     # spot-check one product of the batch against the oracle before timing anything
-    if rank == 0:
+    if rank == 0 and not args.no_check:
         from oracle import pyoracle as po
         O = po.Oracle()
         ah = a[0].cpu().numpy().view(np.uint32)

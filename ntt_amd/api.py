@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnttx.so")
+LIB_PATH = os.environ.get("NTTX_LIB") or os.path.join(_HERE, "csrc", "libnttx.so")  # NTTX_LIB: experiment builds
 
 CRT_PRIMES = (469762049, 998244353, 1004535809, 1224736769)  # main.cc:245-248
 PATH_DIRECT32, PATH_CRT4 = 0, 1

@@ -240,18 +240,34 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
   return 0;
 }
 static int launch_row_raw(int mode, bool lazy, int logT, const RowArgs &A, hipStream_t st) {
+  if (mode == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
+    const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
+    const int grid = grid_for(wgs, 256 * 8);
+    if (lazy) hipLaunchKernelGGL(row_mul9_kernel<true>, dim3(grid), dim3(WG), 0, st, A);
+    else hipLaunchKernelGGL(row_mul9_kernel<false>, dim3(grid), dim3(WG), 0, st, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (mode == ROW_FWD) return lazy ? launch_row_t<ROW_FWD, true>(logT, A, st) : launch_row_t<ROW_FWD, false>(logT, A, st);
   if (mode == ROW_INV) return lazy ? launch_row_t<ROW_INV, true>(logT, A, st) : launch_row_t<ROW_INV, false>(logT, A, st);
   return lazy ? launch_row_t<ROW_MUL, true>(logT, A, st) : launch_row_t<ROW_MUL, false>(logT, A, st);
 }
 
+// Column tile shape: 32 columns (full 128-byte lines) with 512 threads where the tile fits LDS
+// comfortably, 16 columns with 256 threads for the longest column passes.
 template <bool INV, bool LAZY>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  const long long tiles = A.nblocks * ((1ll << A.logS) / COLS);
-#define NTTX_COL_CASE(K) case K: \
-    hipLaunchKernelGGL((col_kernel<K, INV, LAZY>), dim3(grid_for(tiles, 4096), 1, nvec), dim3(WG), 0, st, A); break;
-  switch (logT) {
-    NTTX_COL_CASE(6) NTTX_COL_CASE(7) NTTX_COL_CASE(8) NTTX_COL_CASE(9) NTTX_COL_CASE(10)
+  const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
+  const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
+  const int grid = grid_for(tiles, 2048);
+#define NTTX_COL_CASE(K, LC, NT) \
+    hipLaunchKernelGGL((col_kernel<K, INV, LAZY, LC, NT>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+  switch (logT * 2 + wide) {
+    case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
+    case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
+    case 16: NTTX_COL_CASE(8, 4, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
+    case 18: NTTX_COL_CASE(9, 4, 256)   case 19: NTTX_COL_CASE(9, 5, 512)
+    case 20: NTTX_COL_CASE(10, 4, 256)
     default: return fail(NTTX_ERANGE, "column pass of 2^%d points unsupported", logT);
   }
 #undef NTTX_COL_CASE
@@ -270,7 +286,11 @@ static int launch_row(Context *cx, int mode, bool lazy, int logT, const RowArgs 
   cx->prof.end(st);
   return rc;
 }
-static int launch_col(Context *cx, bool inv, bool lazy, int logT, const ColArgs &A, int nvec, hipStream_t st) {
+static int launch_col(Context *cx, bool inv, bool lazy, int logT, const ColArgs &A0, int nvec, hipStream_t st) {
+  ColArgs A = A0;
+#ifdef NTTX_DBG
+  { const char *e = getenv("NTTX_DBG"); A.dbg = e ? atoi(e) : 0; }
+#endif
   cx->prof.begin(inv ? PK_COL_INV : PK_COL_FWD, st);
   const int rc = launch_col_raw(inv, lazy, logT, A, nvec, st);
   cx->prof.end(st);

@@ -24,8 +24,7 @@
 
 namespace nttx {
 
-constexpr int WG = 256;          // threads per workgroup
-constexpr int COLS = 16;         // contiguous columns per column-pass tile (64 B segments)
+constexpr int WG = 256;          // threads per workgroup of the row kernels
 
 // ------------------------------------------------------------------------------------
 // modular butterflies
@@ -69,6 +68,30 @@ struct Mod {
   __device__ __forceinline__ uint32_t canon(uint32_t x) const { return LAZY ? csub(x, p) : x; }
 };
 
+
+// ------------------------------------------------------------------------------------
+// Radix-8 units on 8 registers: three butterfly stages at point distances 4D, 2D, D.
+// w[m] = tw[lo + m*D] (m = 1..7); UNIT_D1 marks D == 1, where w[1] == 1 needs no product.
+// ------------------------------------------------------------------------------------
+template <bool LAZY, bool UNIT_D1>
+__device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8], const Mod<LAZY> &M) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) M.dif(x[q], x[q + 4], w[4 + q]);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { M.dif(x[q], x[q + 2], w[2 + q]); M.dif(x[4 + q], x[6 + q], w[2 + q]); }
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) { if (!UNIT_D1) M.dif(x[q], x[q + 1], w[1]); else M.dif1(x[q], x[q + 1]); }
+}
+template <bool LAZY, bool UNIT_D1>
+__device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8], const Mod<LAZY> &M) {
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) { if (!UNIT_D1) M.dit(x[q], x[q + 1], w[1]); else M.dit1(x[q], x[q + 1]); }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { M.dit(x[q], x[q + 2], w[2 + q]); M.dit(x[4 + q], x[6 + q], w[2 + q]); }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) M.dit(x[q], x[q + 4], w[4 + q]);
+}
+
 // ------------------------------------------------------------------------------------
 // LDS tile layouts.  A tile holds NT transforms of length T.
 //  RowLayout: transform-contiguous, 8 pad words after every 64 (conflict-free strides 8, 64)
@@ -83,6 +106,7 @@ struct RowLayout {
   static constexpr int TP = T + (T >> 6) * 8;              // padded transform length (words)
   static constexpr int NT = (T >= 2048) ? 1 : (2048 >> LOGT);  // transforms per tile
   static constexpr int WORDS = NT * TP;
+  static constexpr int NTHR = WG;
   __device__ static constexpr int padj(int j) { return j + ((j >> 6) << 3); }
   __device__ static __forceinline__ int addr(int c, int j) { return c * TP + padj(j); }
   // unit index g -> (transform c, unit u): consecutive lanes walk one transform
@@ -90,18 +114,21 @@ struct RowLayout {
   __device__ static __forceinline__ void split(int g, int &c, int &u) { c = g >> LOGU; u = g & ((1 << LOGU) - 1); }
 };
 
-template <int LOGT_>
+// LOGC = log2(contiguous columns per tile): 4 -> 64-byte row segments, 5 -> full 128-byte lines
+template <int LOGT_, int LOGC_, int NTHR_>
 struct ColLayout {
-  static constexpr int LOGT = LOGT_;
+  static constexpr int LOGT = LOGT_, LOGC = LOGC_;
   static constexpr int T = 1 << LOGT;
+  static constexpr int COLS = 1 << LOGC;
   static constexpr int NT = COLS;
+  static constexpr int NTHR = NTHR_;
   static constexpr int ROWS = T + (T >> 3);
   static constexpr int WORDS = ROWS * COLS;
   __device__ static constexpr int padj(int j) { return (j + (j >> 3)) * COLS; }
   __device__ static __forceinline__ int addr(int c, int j) { return padj(j) + c; }
-  // consecutive lanes walk the 16 columns of one unit
+  // consecutive lanes walk the columns of one unit
   template <int LOGU>
-  __device__ static __forceinline__ void split(int g, int &c, int &u) { c = g & (COLS - 1); u = g >> 4; }
+  __device__ static __forceinline__ void split(int g, int &c, int &u) { c = g & (COLS - 1); u = g >> LOGC; }
 };
 
 // ------------------------------------------------------------------------------------
@@ -115,7 +142,7 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
   constexpr int LOG_UNITS = L::LOGT - R;  // log2(units per transform)
   constexpr int TOTAL = L::NT << LOG_UNITS;
   constexpr int NP = 1 << R;
-  for (int g = threadIdx.x; g < TOTAL; g += WG) {
+  for (int g = threadIdx.x; g < TOTAL; g += L::NTHR) {
     int c, u;
     L::template split<LOG_UNITS>(g, c, u);
     const int lo = u & (D - 1), hi = u >> LOGD;
@@ -136,12 +163,7 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
       for (int q = 0; q < NP; ++q) x[q] = s[v][a0 + L::padj(q * D)];
       if constexpr (!INV) {
         if constexpr (R == 3) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) M.dif(x[q], x[q + 4], w[4 + q]);
-#pragma unroll
-          for (int q = 0; q < 2; ++q) { M.dif(x[q], x[q + 2], w[2 + q]); M.dif(x[4 + q], x[6 + q], w[2 + q]); }
-#pragma unroll
-          for (int q = 0; q < 8; q += 2) { if (D > 1) M.dif(x[q], x[q + 1], w[1]); else M.dif1(x[q], x[q + 1]); }
+          r8_dif<LAZY, D == 1>(x, w, M);
         } else if constexpr (R == 2) {
           M.dif(x[0], x[2], w[2]); M.dif(x[1], x[3], w[3]);
           if (D > 1) { M.dif(x[0], x[1], w[1]); M.dif(x[2], x[3], w[1]); }
@@ -151,12 +173,7 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
         }
       } else {
         if constexpr (R == 3) {
-#pragma unroll
-          for (int q = 0; q < 8; q += 2) { if (D > 1) M.dit(x[q], x[q + 1], w[1]); else M.dit1(x[q], x[q + 1]); }
-#pragma unroll
-          for (int q = 0; q < 2; ++q) { M.dit(x[q], x[q + 2], w[2 + q]); M.dit(x[4 + q], x[6 + q], w[2 + q]); }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) M.dit(x[q], x[q + 4], w[4 + q]);
+          r8_dit<LAZY, D == 1>(x, w, M);
         } else if constexpr (R == 2) {
           if (D > 1) { M.dit(x[0], x[1], w[1]); M.dit(x[2], x[3], w[1]); }
           else { M.dit1(x[0], x[1]); M.dit1(x[2], x[3]); }
@@ -302,6 +319,104 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Fused product on 512-point rows, one wavefront per row, no workgroup barrier.
+// Lane l owns 8 points per vector; the three radix-8 rounds use the register layouts
+//   R1: i = l + 64 q         R2: i = 64 (l>>3) + (l&7) + 8 j         R3: i = 8 l + j
+// and move between them through a wave-private LDS buffer (DS operations of one wave
+// execute in order, so a read issued after a write by other lanes sees it).  The last
+// forward round, the pointwise product and the first inverse round all act on the same
+// 8 contiguous points of a lane, so they stay in registers.  Twiddles of a lane do not
+// depend on the row: they are loaded once and stay in registers across the row loop.
+// ------------------------------------------------------------------------------------
+constexpr int ROW9_PAD = 576;  // 512 + 8 pad words per 64
+
+template <bool LAZY>
+__global__ void __launch_bounds__(WG) row_mul9_kernel(RowArgs A) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(WG / 64) * 2 * ROW9_PAD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *sa = lds + wave * 2 * ROW9_PAD, *sb = sa + ROW9_PAD;
+  const Mod<LAZY> M(A.ctx);
+  const int k8 = lane >> 3, m8 = lane & 7;
+  const int o1 = lane;                       // R1: + 72 q
+  const int o2 = 72 * k8 + m8;               // R2: + 8 j
+  const int o3 = 8 * lane + 8 * k8;          // R3: + j (contiguous)
+
+  uint32_t wf1[8], wf2[8], wf3[8], wi1[8], wi2[8], wi3[8];
+#pragma unroll
+  for (int m = 1; m < 8; ++m) {
+    wf1[m] = A.tw_fwd[lane + 64 * m]; wf2[m] = A.tw_fwd[m8 + 8 * m]; wf3[m] = A.tw_fwd[m];
+    wi1[m] = A.tw_inv[lane + 64 * m]; wi2[m] = A.tw_inv[m8 + 8 * m]; wi3[m] = A.tw_inv[m];
+  }
+  wf1[0] = wf2[0] = wf3[0] = wi1[0] = wi2[0] = wi3[0] = 0;
+
+  const long long nwaves = (long long)gridDim.x * (WG / 64);
+  long long row = (long long)blockIdx.x * (WG / 64) + wave;
+  uint32_t na[8], nb[8];
+  if (row < A.nrows) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { na[q] = A.in0[row * 512 + lane + 64 * q]; nb[q] = A.in1[row * 512 + lane + 64 * q]; }
+  }
+  for (; row < A.nrows; row += nwaves) {
+    uint32_t a[8], b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a[q] = na[q]; b[q] = nb[q]; }
+    const long long nrow = row + nwaves;
+    if (nrow < A.nrows) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { na[q] = A.in0[nrow * 512 + lane + 64 * q]; nb[q] = A.in1[nrow * 512 + lane + 64 * q]; }
+    }
+    // forward round 1 (distances 256, 128, 64)
+    r8_dif<LAZY, false>(a, wf1, M);
+    r8_dif<LAZY, false>(b, wf1, M);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sa[o1 + 72 * q] = a[q]; sb[o1 + 72 * q] = b[q]; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = sa[o2 + 8 * j]; b[j] = sb[o2 + 8 * j]; }
+    // forward round 2 (32, 16, 8)
+    r8_dif<LAZY, false>(a, wf2, M);
+    r8_dif<LAZY, false>(b, wf2, M);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sa[o2 + 8 * j] = a[j]; sb[o2 + 8 * j] = b[j]; }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(sa + o3), a1 = *reinterpret_cast<const uint4 *>(sa + o3 + 4);
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(sb + o3), b1 = *reinterpret_cast<const uint4 *>(sb + o3 + 4);
+      a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    }
+    // forward round 3 (4, 2, 1), pointwise product, inverse round 1 (1, 2, 4): all on a lane's own 8 points
+    r8_dif<LAZY, true>(a, wf3, M);
+    r8_dif<LAZY, true>(b, wf3, M);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t pr = M.mul(a[j], b[j]);
+      if (A.scale) pr = M.mul(pr, A.scale);
+      a[j] = pr;
+    }
+    r8_dit<LAZY, true>(a, wi3, M);
+    *reinterpret_cast<uint4 *>(sa + o3) = make_uint4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<uint4 *>(sa + o3 + 4) = make_uint4(a[4], a[5], a[6], a[7]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = sa[o2 + 8 * j];
+    // inverse round 2 (8, 16, 32)
+    r8_dit<LAZY, false>(a, wi2, M);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sa[o2 + 8 * j] = a[j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = sa[o1 + 72 * q];
+    // inverse round 3 (64, 128, 256)
+    r8_dit<LAZY, false>(a, wi1, M);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) A.out[row * 512 + lane + 64 * q] = A.canon_out ? M.canon(a[q]) : a[q];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Column kernels: T points at stride S inside blocks of N = T*S words; a tile is
 // T rows x COLS contiguous columns.  The forward pass multiplies point (j', s) by
@@ -314,56 +429,85 @@ struct ColArgs {
   const uint32_t *tw;     // stage-major table for T (forward or inverse root)
   const uint32_t *fs;     // four-step table, N words
   PrimeCtx ctx;
-  int logS;               // S = 2^logS >= COLS
+  int logS;               // S = 2^logS >= columns per tile
   int canon_out;
   long long nblocks;      // batch * L / N
+#ifdef NTTX_DBG
+  int dbg;                // ablation: 1 = skip butterflies, 2 = skip global loads, 3 = skip global stores
+#endif
 };
 
-template <int LOGT, bool INV, bool LAZY>
-__global__ void __launch_bounds__(WG) col_kernel(ColArgs A) {
-  using L = ColLayout<LOGT>;
-  constexpr int T = L::T;
+// Each thread moves PER = T*COLS/(4*NTHR) 16-byte pieces of a tile; LPR = COLS/4 lanes cover one
+// row segment.  The next tile's pieces are fetched into registers before the butterflies of the
+// current tile start, so HBM latency overlaps with compute inside one workgroup.
+template <int LOGT, bool INV, bool LAZY, int LOGC, int NTHR>
+__global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
+  using L = ColLayout<LOGT, LOGC, NTHR>;
+  constexpr int T = L::T, COLS = L::COLS;
+  constexpr int LPR = COLS / 4, LOG_LPR = LOGC - 2;
+  constexpr int PER = (T * LPR) / NTHR;
+  constexpr int RSTEP = NTHR / LPR;              // rows covered by one piece index
+  static_assert(PER >= 1 && PER * NTHR == T * LPR, "tile must be a whole number of pieces per thread");
   __shared__ __attribute__((aligned(16))) uint32_t lds[L::WORDS + T];
   uint32_t *s = lds, *tw = lds + L::WORDS;
   const Mod<LAZY> M(A.ctx);
   const uint32_t *in = A.in[blockIdx.z];
   uint32_t *out = A.out[blockIdx.z];
-  const long long S = 1ll << A.logS;
-  const int tiles_per_block = (int)(S / COLS);
-  const long long ntiles = A.nblocks * tiles_per_block;
+  const int logS = A.logS;
+  const int log_tpb = logS - LOGC;               // log2(tiles per block)
+  const long long ntiles = A.nblocks << log_tpb;
+  const int j0 = threadIdx.x >> LOG_LPR, c4 = (threadIdx.x & (LPR - 1)) * 4;
 
-  for (int i = threadIdx.x; i < T; i += WG) tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < T; i += NTHR) tw[i] = A.tw[i];
 
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long long blk = t / tiles_per_block;
-    const int ct = (int)(t - blk * tiles_per_block);
-    const long long gbase = blk * (S << LOGT) + (long long)ct * COLS;
-    const long long fbase = (long long)ct * COLS;
-    __syncthreads();
-    // load: 4 lanes cover one 64-byte row segment
-    for (int v = threadIdx.x; v < T * (COLS / 4); v += WG) {
-      const int j = v >> 2, c4 = (v & 3) * 4;
-      uint4 x = *reinterpret_cast<const uint4 *>(in + gbase + j * S + c4);
+  auto tile_base = [&](long long t) -> long long {
+    const long long blk = t >> log_tpb;
+    const long long ct = t & ((1ll << log_tpb) - 1);
+    return (blk << (logS + LOGT)) + (ct << LOGC);
+  };
+  auto fs_base = [&](long long t) -> long long { return (t & ((1ll << log_tpb) - 1)) << LOGC; };
+
+  uint4 nx[PER];
+  long long t = blockIdx.x;
+  if (t < ntiles) {
+    const uint32_t *src = in + tile_base(t) + c4;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) nx[k] = *reinterpret_cast<const uint4 *>(src + ((long long)(j0 + k * RSTEP) << logS));
+  }
+  for (; t < ntiles; t += gridDim.x) {
+    const long long gbase = tile_base(t), fbase = fs_base(t);
+    __syncthreads();   // previous tile's LDS reads are done
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      uint4 x = nx[k];
+      const int j = j0 + k * RSTEP;
       if (INV) {
-        const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + j * S + c4);
+        const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
         x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y); x.z = M.mul(x.z, f.z); x.w = M.mul(x.w, f.w);
       }
       *reinterpret_cast<uint4 *>(s + L::addr(c4, j)) = x;
+    }
+    const long long tn = t + gridDim.x;
+    if (tn < ntiles) {
+      const uint32_t *src = in + tile_base(tn) + c4;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) nx[k] = *reinterpret_cast<const uint4 *>(src + ((long long)(j0 + k * RSTEP) << logS));
     }
     __syncthreads();
     uint32_t *const vec[1] = {s};
     if (!INV) dif_rounds<L, LOGT, LAZY, 1>(vec, tw, M);
     else dit_rounds<L, LOGT, LAZY, 1>(vec, tw, M);
     __syncthreads();
-    for (int v = threadIdx.x; v < T * (COLS / 4); v += WG) {
-      const int j = v >> 2, c4 = (v & 3) * 4;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int j = j0 + k * RSTEP;
       uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c4, j));
       if (!INV) {
-        const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + j * S + c4);
+        const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
         x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y); x.z = M.mul(x.z, f.z); x.w = M.mul(x.w, f.w);
       }
       if (A.canon_out) { x.x = M.canon(x.x); x.y = M.canon(x.y); x.z = M.canon(x.z); x.w = M.canon(x.w); }
-      *reinterpret_cast<uint4 *>(out + gbase + j * S + c4) = x;
+      *reinterpret_cast<uint4 *>(out + gbase + ((long long)j << logS) + c4) = x;
     }
   }
 }
