@@ -56,7 +56,7 @@ struct DevBuf {
 
 // ---- plan: decomposition + device tables for one (p, log2 length, root direction) -----
 struct Plan {
-  uint32_t p = 0; int logL = 0; bool conj = false; bool lazy = false;
+  uint32_t p = 0; int logL = 0; bool conj = false; int hclass = 2;  // multiples of p below 2^32: 2, 4 or 9
   PrimeCtx ctx{};
   int npass = 0; int lt[3] = {0, 0, 0};     // lt[0..npass-2] column passes, lt[npass-1] the row pass
   uint32_t *tw_fwd[3] = {nullptr, nullptr, nullptr};  // stage-major tables per pass, root w
@@ -126,6 +126,8 @@ struct Context {
   DevBuf pa, pb, pc;        // padded residues / product [nprimes][batch][len]
   DevBuf outb;              // compacted output staged for the copy back
   DevBuf tmp;               // transform API scratch
+  hipStream_t aux[2] = {nullptr, nullptr};   // side streams for pipelining launch groups
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
 static Context *g_ctx = nullptr;
 static std::mutex g_init_mu;
@@ -191,7 +193,8 @@ static int get_plan(Context *cx, uint32_t p, int logL, bool conj, Plan **out) {
   if (it != cx->plans.end()) { *out = it->second.get(); return 0; }
   if (!direct_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %u does not support a direct length-2^%d transform", p, logL);
   std::unique_ptr<Plan> pl(new Plan);
-  pl->p = p; pl->logL = logL; pl->conj = conj; pl->lazy = p < (1u << 30);
+  pl->p = p; pl->logL = logL; pl->conj = conj;
+  pl->hclass = (9ull * p < (1ull << 32)) ? 9 : (p < (1u << 30)) ? 4 : 2;
   pl->ctx = make_ctx(p);
   pl->npass = decompose(logL, pl->lt);
   const uint32_t g = find_nonresidue(p);
@@ -222,14 +225,22 @@ static int get_plan(Context *cx, uint32_t p, int logL, bool conj, Plan **out) {
 }
 
 // ---- kernel dispatch -------------------------------------------------------------------
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static int grid_for(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
 
-template <int MODE, bool LAZY>
+template <int MODE, int H>
 static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
+  if (MODE == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
+    const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
+    static const int cap9 = env_int("NTTX_GRID_ROW", 256 * 8);
+    hipLaunchKernelGGL(row_mul9_kernel<H>, dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
 #define NTTX_ROW_CASE(K) case K: { \
     using Lyt = RowLayout<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    hipLaunchKernelGGL((row_kernel<K, MODE, LAZY>), dim3(grid_for(tiles, 8192)), dim3(WG), 0, st, A); break; }
+    hipLaunchKernelGGL((row_kernel<K, MODE, H>), dim3(grid_for(tiles, 8192)), dim3(WG), 0, st, A); break; }
   switch (logT) {
     NTTX_ROW_CASE(1) NTTX_ROW_CASE(2) NTTX_ROW_CASE(3) NTTX_ROW_CASE(4) NTTX_ROW_CASE(5) NTTX_ROW_CASE(6)
     NTTX_ROW_CASE(7) NTTX_ROW_CASE(8) NTTX_ROW_CASE(9) NTTX_ROW_CASE(10) NTTX_ROW_CASE(11)
@@ -239,29 +250,26 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_row_raw(int mode, bool lazy, int logT, const RowArgs &A, hipStream_t st) {
-  if (mode == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
-    const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
-    const int grid = grid_for(wgs, 256 * 8);
-    if (lazy) hipLaunchKernelGGL(row_mul9_kernel<true>, dim3(grid), dim3(WG), 0, st, A);
-    else hipLaunchKernelGGL(row_mul9_kernel<false>, dim3(grid), dim3(WG), 0, st, A);
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
-  if (mode == ROW_FWD) return lazy ? launch_row_t<ROW_FWD, true>(logT, A, st) : launch_row_t<ROW_FWD, false>(logT, A, st);
-  if (mode == ROW_INV) return lazy ? launch_row_t<ROW_INV, true>(logT, A, st) : launch_row_t<ROW_INV, false>(logT, A, st);
-  return lazy ? launch_row_t<ROW_MUL, true>(logT, A, st) : launch_row_t<ROW_MUL, false>(logT, A, st);
+template <int MODE>
+static int launch_row_m(int h, int logT, const RowArgs &A, hipStream_t st) {
+  return h == 9 ? launch_row_t<MODE, 9>(logT, A, st) : h == 4 ? launch_row_t<MODE, 4>(logT, A, st) : launch_row_t<MODE, 2>(logT, A, st);
+}
+static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream_t st) {
+  if (mode == ROW_FWD) return launch_row_m<ROW_FWD>(h, logT, A, st);
+  if (mode == ROW_INV) return launch_row_m<ROW_INV>(h, logT, A, st);
+  return launch_row_m<ROW_MUL>(h, logT, A, st);
 }
 
 // Column tile shape: 32 columns (full 128-byte lines) with 512 threads where the tile fits LDS
 // comfortably, 16 columns with 256 threads for the longest column passes.
-template <bool INV, bool LAZY>
+template <bool INV, int H>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
   const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
-  const int grid = grid_for(tiles, 2048);
+  static const int capc = env_int("NTTX_GRID_COL", 2048);
+  const int grid = grid_for(tiles, std::max(1, capc / nvec));
 #define NTTX_COL_CASE(K, LC, NT) \
-    hipLaunchKernelGGL((col_kernel<K, INV, LAZY, LC, NT>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
   switch (logT * 2 + wide) {
     case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
     case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
@@ -274,25 +282,26 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_col_raw(bool inv, bool lazy, int logT, const ColArgs &A, int nvec, hipStream_t st) {
+template <bool INV>
+static int launch_col_i(int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
+  return h == 9 ? launch_col_t<INV, 9>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4>(logT, A, nvec, st)
+                                                                   : launch_col_t<INV, 2>(logT, A, nvec, st);
+}
+static int launch_col_raw(bool inv, int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
   if (logT < kMinColLog || A.logS < 4) return fail(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
-  if (!inv) return lazy ? launch_col_t<false, true>(logT, A, nvec, st) : launch_col_t<false, false>(logT, A, nvec, st);
-  return lazy ? launch_col_t<true, true>(logT, A, nvec, st) : launch_col_t<true, false>(logT, A, nvec, st);
+  return inv ? launch_col_i<true>(h, logT, A, nvec, st) : launch_col_i<false>(h, logT, A, nvec, st);
 }
 
-static int launch_row(Context *cx, int mode, bool lazy, int logT, const RowArgs &A, hipStream_t st) {
+static int launch_row(Context *cx, int mode, int h, int logT, const RowArgs &A, hipStream_t st) {
   cx->prof.begin(mode == ROW_MUL ? PK_ROW_MUL : mode == ROW_FWD ? PK_ROW_FWD : PK_ROW_INV, st);
-  const int rc = launch_row_raw(mode, lazy, logT, A, st);
+  const int rc = launch_row_raw(mode, h, logT, A, st);
   cx->prof.end(st);
   return rc;
 }
-static int launch_col(Context *cx, bool inv, bool lazy, int logT, const ColArgs &A0, int nvec, hipStream_t st) {
-  ColArgs A = A0;
-#ifdef NTTX_DBG
-  { const char *e = getenv("NTTX_DBG"); A.dbg = e ? atoi(e) : 0; }
-#endif
+static int launch_col(Context *cx, bool inv, int h, int logT, const ColArgs &A0, int nvec, hipStream_t st) {
+  const ColArgs &A = A0;
   cx->prof.begin(inv ? PK_COL_INV : PK_COL_FWD, st);
-  const int rc = launch_col_raw(inv, lazy, logT, A, nvec, st);
+  const int rc = launch_col_raw(inv, h, logT, A, nvec, st);
   cx->prof.end(st);
   return rc;
 }
@@ -301,6 +310,15 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 
 // ---- device-resident building blocks ---------------------------------------------------
 
+// Multiplications per launch group of a multi-pass batch (default: the whole batch).
+static int chunk_for(int logL, int batch) {
+  static int forced = [] { const char *e = getenv("NTTX_CHUNK"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return std::min(forced, batch);
+  (void)logL;
+  return batch;   // measured on MI355X: splitting a resident batch into cache-sized launches loses more
+                  // to short launches than residency wins; NTTX_CHUNK keeps the knob for experiments
+}
+
 // c = cyclic product of a and b, all [batch][2^logL] u32 on the device
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
                                hipStream_t st) {
@@ -308,31 +326,57 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
   if (pl->npass == 1) {
     RowArgs R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
     R.ctx = pl->ctx; R.scale = pl->scale_single; R.canon_out = 1; R.nrows = batch;
-    return launch_row(cx, ROW_MUL, pl->lazy, pl->lt[0], R, st);
+    return launch_row(cx, ROW_MUL, pl->hclass, pl->lt[0], R, st);
   }
-  if (int rc = cx->wa.ensure((size_t)batch * len * 4)) return rc;
-  if (int rc = cx->wb.ensure((size_t)batch * len * 4)) return rc;
-  uint32_t *wa = cx->wa.as<uint32_t>(), *wb = cx->wb.as<uint32_t>();
-  int logN = pl->logL;
+  // Launch groups.  With NTTX_SPLIT=G > 1 the batch is cut into G groups whose three-kernel chains are
+  // issued alternately on two side streams, so the memory-bound column passes of one group can overlap
+  // the VALU-bound row pass of the other.
+  static const int split = env_int("NTTX_SPLIT", 1);
+  const int groups = (split > 1 && batch >= 2 * split) ? split : 1;
+  const int chunk = groups > 1 ? (batch + groups - 1) / groups : chunk_for(pl->logL, batch);
+  const size_t wsz = (size_t)(groups > 1 ? batch : chunk) * len * 4;
+  if (int rc = cx->wa.ensure(wsz)) return rc;
+  if (int rc = cx->wb.ensure(wsz)) return rc;
+  if (groups > 1) {
+    if (!cx->aux[0]) {
+      for (int i = 0; i < 2; ++i) { HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming)); }
+      HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(cx->ev_fork, st));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
+  }
   const int ncol = pl->npass - 1;
-  for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
-    ColArgs C{}; C.in[0] = lv == 0 ? a : wa; C.in[1] = lv == 0 ? b : wb; C.out[0] = wa; C.out[1] = wb;
-    C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
-    C.nblocks = ((long long)batch << pl->logL) >> logN;
-    if (int rc = launch_col(cx, false, pl->lazy, pl->lt[lv], C, 2, st)) return rc;
-    logN = C.logS;
+  int gi = 0;
+  for (int b0 = 0; b0 < batch; b0 += chunk, ++gi) {
+    const int nb = std::min(chunk, batch - b0);
+    hipStream_t gs = groups > 1 ? cx->aux[gi & 1] : st;
+    const size_t woff = groups > 1 ? (size_t)b0 * len : 0;
+    uint32_t *wa = cx->wa.as<uint32_t>() + woff, *wb = cx->wb.as<uint32_t>() + woff;
+    const uint32_t *ca = a + (size_t)b0 * len, *cb = b + (size_t)b0 * len;
+    uint32_t *cc = c + (size_t)b0 * len;
+    int logN = pl->logL;
+    for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
+      ColArgs C{}; C.in[0] = lv == 0 ? ca : wa; C.in[1] = lv == 0 ? cb : wb; C.out[0] = wa; C.out[1] = wb;
+      C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
+      C.nblocks = ((long long)nb << pl->logL) >> logN;
+      if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, gs)) return rc;
+      logN = C.logS;
+    }
+    {                                              // rows: forward a, forward b, pointwise, inverse
+      RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = cc; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
+      R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)nb << pl->logL) >> pl->lt[ncol];
+      if (int rc = launch_row(cx, ROW_MUL, pl->hclass, pl->lt[ncol], R, gs)) return rc;
+    }
+    for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
+      int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
+      ColArgs C{}; C.in[0] = cc; C.in[1] = nullptr; C.out[0] = cc; C.out[1] = nullptr;
+      C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
+      C.nblocks = ((long long)nb << pl->logL) >> logNl;
+      if (int rc = launch_col(cx, true, pl->hclass, pl->lt[lv], C, 1, gs)) return rc;
+    }
   }
-  {                                              // rows: forward a, forward b, pointwise, inverse
-    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
-    R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
-    if (int rc = launch_row(cx, ROW_MUL, pl->lazy, pl->lt[ncol], R, st)) return rc;
-  }
-  for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
-    int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
-    ColArgs C{}; C.in[0] = c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
-    C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
-    C.nblocks = ((long long)batch << pl->logL) >> logNl;
-    if (int rc = launch_col(cx, true, pl->lazy, pl->lt[lv], C, 1, st)) return rc;
+  if (groups > 1) {
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipEventRecord(cx->ev_join[i], cx->aux[i])); HIPCHK(hipStreamWaitEvent(st, cx->ev_join[i], 0)); }
   }
   return 0;
 }
@@ -344,12 +388,12 @@ static int dev_forward(Context *cx, Plan *pl, uint32_t *x, int batch, bool canon
   for (int lv = 0; lv < ncol; ++lv) {
     ColArgs C{}; C.in[0] = x; C.out[0] = x; C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx;
     C.logS = logN - pl->lt[lv]; C.canon_out = 0; C.nblocks = ((long long)batch << pl->logL) >> logN;
-    if (int rc = launch_col(cx, false, pl->lazy, pl->lt[lv], C, 1, st)) return rc;
+    if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 1, st)) return rc;
     logN = C.logS;
   }
   RowArgs R{}; R.in0 = x; R.out = x; R.tw_fwd = pl->tw_fwd[ncol]; R.ctx = pl->ctx; R.canon_out = canon;
   R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
-  return launch_row(cx, ROW_FWD, pl->lazy, pl->lt[ncol], R, st);
+  return launch_row(cx, ROW_FWD, pl->hclass, pl->lt[ncol], R, st);
 }
 
 // ---- CRT constants (main.cc:256-270 computes M, K_i = M/m_i, K_i^{-1} mod m_i; the Garner
@@ -471,6 +515,8 @@ void nttx_shutdown(void) {
   (void)hipDeviceSynchronize();
   g_ctx->plans.clear();
   g_ctx->prof.destroy();
+  for (int i = 0; i < 2; ++i) { if (g_ctx->aux[i]) (void)hipStreamDestroy(g_ctx->aux[i]); if (g_ctx->ev_join[i]) (void)hipEventDestroy(g_ctx->ev_join[i]); }
+  if (g_ctx->ev_fork) (void)hipEventDestroy(g_ctx->ev_fork);
   for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
     b->release();
   delete g_ctx;
@@ -517,8 +563,10 @@ int nttx_reserve(int len, int batch, int nprimes) {
   NTTX_ENTER();
   if (len < 2 || batch < 1 || nprimes < 1 || nprimes > 4) return fail(NTTX_EINVAL, "bad arguments");
   const size_t vec = (size_t)batch * len * 4;
-  if (int rc = cx->wa.ensure(vec)) return rc;
-  if (int rc = cx->wb.ensure(vec)) return rc;
+  int k = 0; while ((1ll << k) < len) ++k;
+  const size_t wvec = (size_t)chunk_for(k, batch) * len * 4;
+  if (int rc = cx->wa.ensure(wvec)) return rc;
+  if (int rc = cx->wb.ensure(wvec)) return rc;
   if (nprimes > 1) {
     if (int rc = cx->pa.ensure(nprimes * vec)) return rc;
     if (int rc = cx->pb.ensure(nprimes * vec)) return rc;

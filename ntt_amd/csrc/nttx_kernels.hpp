@@ -8,15 +8,20 @@
 // Structure (MI355X-first, not a translation):
 //  * A length-L transform is factored L = T1*T2(*T3) ("four-step"): strided
 //    column passes of length T1 (T2) followed by contiguous row passes, every
-//    pass doing all of its log2(T) butterfly stages inside LDS.
+//    pass doing all of its log2(T) butterfly stages on chip.
 //  * Forward passes are decimation-in-frequency (natural in, bit-reversed out),
 //    inverse passes decimation-in-time (bit-reversed in, natural out), so the
 //    fused multiply never runs a bit-reversal permutation.
 //  * Inside a pass each thread owns a radix-8 (or 4/2) unit: 8 points in
 //    registers, 3 stages, then one exchange through LDS.
 //  * Residues are 32-bit, Montgomery radix 2^32; twiddles are precomputed in
-//    Montgomery form. Between stages values are kept lazily in [0,2p) when
-//    p < 2^30 and canonically in [0,p) otherwise.
+//    Montgomery form.  Values are reduced lazily: every register value carries a
+//    compile-time bound (a multiple of p) and a conditional subtraction is emitted
+//    only where a sum would otherwise leave the 32-bit lane.
+//
+// Measured gfx950 issue costs behind these choices (cycles per wave64 instruction per
+// SIMD with >= 2 waves): v_add/v_sub 2.5, v_min_u32 4.2, v_mul_lo_u32 4.2,
+// v_mad_u64_u32 4.5.  The path is integer-VALU bound, not MFMA material.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,69 +32,153 @@ namespace nttx {
 constexpr int WG = 256;          // threads per workgroup of the row kernels
 
 // ------------------------------------------------------------------------------------
-// modular butterflies
+// Bounded lazy arithmetic.  V<K> holds a value v < K*p.  H = how many multiples of p are
+// known to fit below 2^32 for the modulus class: 2 (p < 2^31), 4 (p < 2^30), 9 (p < 2^32/9).
 // ------------------------------------------------------------------------------------
-template <bool LAZY>
-struct Mod {
-  uint32_t p, npinv, m;  // m = representation bound: 2p (lazy) or p (canonical)
-  __device__ __forceinline__ Mod(const PrimeCtx &c) : p(c.p), npinv(c.npinv), m(LAZY ? 2 * c.p : c.p) {}
-  __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) const { return csub(a + b, m); }
-  __device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) const {
-    uint32_t d = a - b, e = d + m;   // d wraps when a < b; then e = d + m is the small value
-    return d < e ? d : e;
+template <int K>
+struct V { uint32_t v; };
+template <class A, class B>
+struct Pair { A a; B b; };
+template <class A, class B>
+__device__ __forceinline__ Pair<A, B> mkpair(A a, B b) { return Pair<A, B>{a, b}; }
+
+template <int H>
+struct Arith {
+  // Bounds kept by values that cross an LDS exchange or a kernel boundary, per direction.  Chosen
+  // by counting the conditional subtractions a radix-8 unit needs under each contract (forward
+  // units want small inputs because sums add bounds; inverse units only ever add 2p per stage).
+  static constexpr int KF = (H >= 9) ? 4 : 2;   // forward (decimation-in-frequency) passes
+  static constexpr int KI = (H >= 4) ? 4 : 2;   // inverse (decimation-in-time) passes
+  uint32_t p, npinv;
+  __device__ __forceinline__ Arith(const PrimeCtx &c) : p(c.p), npinv(c.npinv) {}
+  template <int C>
+  __device__ __forceinline__ uint32_t kp() const { return (uint32_t)C * p; }   // scalar, hoisted
+  // one conditional subtraction: [0, K p) -> [0, ceil(K/2) p)
+  template <int K>
+  __device__ __forceinline__ V<(K + 1) / 2> half(V<K> x) const {
+    return V<(K + 1) / 2>{csub(x.v, kp<(K + 1) / 2>())};
   }
-  // x*w with w canonical Montgomery-form constant; x any value below 2^32
-  __device__ __forceinline__ uint32_t mul(uint32_t x, uint32_t w) const {
-    uint32_t t = mont_mul_lazy(x, w, p, npinv);
-    return LAZY ? t : csub(t, p);
+  template <int T, int K>
+  __device__ __forceinline__ auto reduce(V<K> x) const {
+    if constexpr (K <= T) return x; else return reduce<T>(half(x));
   }
-  // decimation-in-frequency (Gentleman-Sande): (a, b) -> (a + b, (a - b) * w)
-  __device__ __forceinline__ void dif(uint32_t &a, uint32_t &b, uint32_t w) const {
-    uint32_t s = add(a, b);
-    b = mul(a - b + m, w);
-    a = s;
+  // x * w, w a canonical Montgomery-form constant: any 32-bit x is admissible
+  template <int K>
+  __device__ __forceinline__ V<2> mul(V<K> x, uint32_t w) const { return V<2>{mont_mul_lazy(x.v, w, p, npinv)}; }
+  // data * data: needs a*b < 2^32 p, i.e. KA*KB <= H
+  template <int KA, int KB>
+  __device__ __forceinline__ V<2> mul2(V<KA> a, V<KB> b) const {
+    if constexpr (KA * KB <= H) return V<2>{mont_mul_lazy(a.v, b.v, p, npinv)};
+    else if constexpr (KA >= KB) return mul2(half(a), b);
+    else return mul2(a, half(b));
   }
-  __device__ __forceinline__ void dif1(uint32_t &a, uint32_t &b) const {  // twiddle 1
-    uint32_t s = add(a, b);
-    b = sub(a, b);
-    a = s;
+  // Gentleman-Sande butterfly (a, b) -> (a + b, (a - b) w)
+  template <int KA, int KB>
+  __device__ __forceinline__ auto dif(V<KA> a, V<KB> b, uint32_t w) const {
+    if constexpr (KA + KB <= H) return mkpair(V<KA + KB>{a.v + b.v}, mul(V<KA + KB>{a.v - b.v + kp<KB>()}, w));
+    else if constexpr (KA >= KB) return dif(half(a), b, w);
+    else return dif(a, half(b), w);
   }
-  // decimation-in-time (Cooley-Tukey): (a, b) -> (a + b*w, a - b*w)
-  __device__ __forceinline__ void dit(uint32_t &a, uint32_t &b, uint32_t w) const {
-    uint32_t v = mul(b, w);
-    b = sub(a, v);
-    a = add(a, v);
+  // twiddle 1: (a + b, a - b), used by both directions
+  template <int KA, int KB>
+  __device__ __forceinline__ auto bf1(V<KA> a, V<KB> b) const {
+    if constexpr (KA + KB <= H) return mkpair(V<KA + KB>{a.v + b.v}, V<KA + KB>{a.v - b.v + kp<KB>()});
+    else if constexpr (KA >= KB) return bf1(half(a), b);
+    else return bf1(a, half(b));
   }
-  __device__ __forceinline__ void dit1(uint32_t &a, uint32_t &b) const {
-    uint32_t v = b;
-    b = sub(a, v);
-    a = add(a, v);
-  }
-  __device__ __forceinline__ uint32_t canon(uint32_t x) const { return LAZY ? csub(x, p) : x; }
+  // Cooley-Tukey butterfly (a, b) -> (a + b w, a - b w); b may carry any bound
+  template <int KA, int KB>
+  __device__ __forceinline__ auto dit(V<KA> a, V<KB> b, uint32_t w) const { return bf1(a, mul(b, w)); }
+  template <int K>
+  __device__ __forceinline__ uint32_t canon(V<K> x) const { return reduce<1>(x).v; }
+  template <bool INV, int K>
+  __device__ __forceinline__ uint32_t lazy(V<K> x) const { return reduce<(INV ? KI : KF)>(x).v; }
+  // a value read back under the forward / inverse contract
+  __device__ __forceinline__ V<KF> inF(uint32_t x) const { return V<KF>{x}; }
+  __device__ __forceinline__ V<KI> inI(uint32_t x) const { return V<KI>{x}; }
 };
 
-
 // ------------------------------------------------------------------------------------
-// Radix-8 units on 8 registers: three butterfly stages at point distances 4D, 2D, D.
-// w[m] = tw[lo + m*D] (m = 1..7); UNIT_D1 marks D == 1, where w[1] == 1 needs no product.
+// Radix-8 / 4 / 2 units on registers: stages at point distances 4D, 2D, D.
+// w[m] = tw[lo + m*D]; UNIT_D1 marks D == 1 where the twiddles of index 0 equal 1
+// (w[1], w[2], w[4]) and their products are skipped.  x[] holds values below KF*p (forward) or
+// KI*p (inverse) on entry and on exit.
 // ------------------------------------------------------------------------------------
-template <bool LAZY, bool UNIT_D1>
-__device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8], const Mod<LAZY> &M) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) M.dif(x[q], x[q + 4], w[4 + q]);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) { M.dif(x[q], x[q + 2], w[2 + q]); M.dif(x[4 + q], x[6 + q], w[2 + q]); }
-#pragma unroll
-  for (int q = 0; q < 8; q += 2) { if (!UNIT_D1) M.dif(x[q], x[q + 1], w[1]); else M.dif1(x[q], x[q + 1]); }
+template <int H, bool UNIT_D1>
+__device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8], const Arith<H> &M) {
+  const V<Arith<H>::KF> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
+  // distance 4D
+  const auto p04 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i4); else return M.dif(i0, i4, w[4]); }();
+  const auto p15 = M.dif(i1, i5, w[5]);
+  const auto p26 = M.dif(i2, i6, w[6]);
+  const auto p37 = M.dif(i3, i7, w[7]);
+  // distance 2D
+  const auto q02 = [&] { if constexpr (UNIT_D1) return M.bf1(p04.a, p26.a); else return M.dif(p04.a, p26.a, w[2]); }();
+  const auto q13 = M.dif(p15.a, p37.a, w[3]);
+  const auto q46 = [&] { if constexpr (UNIT_D1) return M.bf1(p04.b, p26.b); else return M.dif(p04.b, p26.b, w[2]); }();
+  const auto q57 = M.dif(p15.b, p37.b, w[3]);
+  // distance D
+  const auto r01 = [&] { if constexpr (UNIT_D1) return M.bf1(q02.a, q13.a); else return M.dif(q02.a, q13.a, w[1]); }();
+  const auto r23 = [&] { if constexpr (UNIT_D1) return M.bf1(q02.b, q13.b); else return M.dif(q02.b, q13.b, w[1]); }();
+  const auto r45 = [&] { if constexpr (UNIT_D1) return M.bf1(q46.a, q57.a); else return M.dif(q46.a, q57.a, w[1]); }();
+  const auto r67 = [&] { if constexpr (UNIT_D1) return M.bf1(q46.b, q57.b); else return M.dif(q46.b, q57.b, w[1]); }();
+  x[0] = M.template lazy<false>(r01.a); x[1] = M.template lazy<false>(r01.b); x[2] = M.template lazy<false>(r23.a); x[3] = M.template lazy<false>(r23.b);
+  x[4] = M.template lazy<false>(r45.a); x[5] = M.template lazy<false>(r45.b); x[6] = M.template lazy<false>(r67.a); x[7] = M.template lazy<false>(r67.b);
 }
-template <bool LAZY, bool UNIT_D1>
-__device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8], const Mod<LAZY> &M) {
-#pragma unroll
-  for (int q = 0; q < 8; q += 2) { if (!UNIT_D1) M.dit(x[q], x[q + 1], w[1]); else M.dit1(x[q], x[q + 1]); }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) { M.dit(x[q], x[q + 2], w[2 + q]); M.dit(x[4 + q], x[6 + q], w[2 + q]); }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) M.dit(x[q], x[q + 4], w[4 + q]);
+
+template <int H, bool UNIT_D1>
+__device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8], const Arith<H> &M) {
+  const V<Arith<H>::KI> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
+  // distance D
+  const auto p01 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i1); else return M.dit(i0, i1, w[1]); }();
+  const auto p23 = [&] { if constexpr (UNIT_D1) return M.bf1(i2, i3); else return M.dit(i2, i3, w[1]); }();
+  const auto p45 = [&] { if constexpr (UNIT_D1) return M.bf1(i4, i5); else return M.dit(i4, i5, w[1]); }();
+  const auto p67 = [&] { if constexpr (UNIT_D1) return M.bf1(i6, i7); else return M.dit(i6, i7, w[1]); }();
+  // distance 2D
+  const auto q02 = [&] { if constexpr (UNIT_D1) return M.bf1(p01.a, p23.a); else return M.dit(p01.a, p23.a, w[2]); }();
+  const auto q13 = M.dit(p01.b, p23.b, w[3]);
+  const auto q46 = [&] { if constexpr (UNIT_D1) return M.bf1(p45.a, p67.a); else return M.dit(p45.a, p67.a, w[2]); }();
+  const auto q57 = M.dit(p45.b, p67.b, w[3]);
+  // distance 4D
+  const auto r04 = [&] { if constexpr (UNIT_D1) return M.bf1(q02.a, q46.a); else return M.dit(q02.a, q46.a, w[4]); }();
+  const auto r15 = M.dit(q13.a, q57.a, w[5]);
+  const auto r26 = M.dit(q02.b, q46.b, w[6]);
+  const auto r37 = M.dit(q13.b, q57.b, w[7]);
+  x[0] = M.template lazy<true>(r04.a); x[4] = M.template lazy<true>(r04.b); x[1] = M.template lazy<true>(r15.a); x[5] = M.template lazy<true>(r15.b);
+  x[2] = M.template lazy<true>(r26.a); x[6] = M.template lazy<true>(r26.b); x[3] = M.template lazy<true>(r37.a); x[7] = M.template lazy<true>(r37.b);
+}
+
+template <int H, bool UNIT_D1, bool INV>
+__device__ __forceinline__ void r4_unit(uint32_t (&x)[4], const uint32_t (&w)[4], const Arith<H> &M) {
+  const V<(INV ? Arith<H>::KI : Arith<H>::KF)> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]};
+  if constexpr (!INV) {
+    const auto p02 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i2); else return M.dif(i0, i2, w[2]); }();
+    const auto p13 = M.dif(i1, i3, w[3]);
+    const auto q01 = [&] { if constexpr (UNIT_D1) return M.bf1(p02.a, p13.a); else return M.dif(p02.a, p13.a, w[1]); }();
+    const auto q23 = [&] { if constexpr (UNIT_D1) return M.bf1(p02.b, p13.b); else return M.dif(p02.b, p13.b, w[1]); }();
+    x[0] = M.template lazy<INV>(q01.a); x[1] = M.template lazy<INV>(q01.b); x[2] = M.template lazy<INV>(q23.a); x[3] = M.template lazy<INV>(q23.b);
+  } else {
+    const auto p01 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i1); else return M.dit(i0, i1, w[1]); }();
+    const auto p23 = [&] { if constexpr (UNIT_D1) return M.bf1(i2, i3); else return M.dit(i2, i3, w[1]); }();
+    const auto q02 = [&] { if constexpr (UNIT_D1) return M.bf1(p01.a, p23.a); else return M.dit(p01.a, p23.a, w[2]); }();
+    const auto q13 = M.dit(p01.b, p23.b, w[3]);
+    x[0] = M.template lazy<INV>(q02.a); x[2] = M.template lazy<INV>(q02.b); x[1] = M.template lazy<INV>(q13.a); x[3] = M.template lazy<INV>(q13.b);
+  }
+}
+
+template <int H, bool UNIT_D1, bool INV>
+__device__ __forceinline__ void r2_unit(uint32_t (&x)[2], const uint32_t (&w)[2], const Arith<H> &M) {
+  const V<(INV ? Arith<H>::KI : Arith<H>::KF)> i0{x[0]}, i1{x[1]};
+  if constexpr (UNIT_D1) {
+    const auto r = M.bf1(i0, i1);
+    x[0] = M.template lazy<INV>(r.a); x[1] = M.template lazy<INV>(r.b);
+  } else if constexpr (!INV) {
+    const auto r = M.dif(i0, i1, w[1]);
+    x[0] = M.template lazy<INV>(r.a); x[1] = M.template lazy<INV>(r.b);
+  } else {
+    const auto r = M.dit(i0, i1, w[1]);
+    x[0] = M.template lazy<INV>(r.a); x[1] = M.template lazy<INV>(r.b);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -136,8 +225,8 @@ struct ColLayout {
 // the tile, for NV vectors that share twiddles (a and b of a product).
 // tw is the stage-major table: tw[h + j] = g^(j*T/(2h)), j < h, Montgomery form.
 // ------------------------------------------------------------------------------------
-template <class L, int R, int LOGD, bool INV, bool LAZY, int NV>
-__device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32_t *tw, const Mod<LAZY> &M) {
+template <class L, int R, int LOGD, bool INV, int H, int NV>
+__device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   constexpr int D = 1 << LOGD;
   constexpr int LOG_UNITS = L::LOGT - R;  // log2(units per transform)
   constexpr int TOTAL = L::NT << LOG_UNITS;
@@ -149,38 +238,20 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
     const int base = (hi << (LOGD + R)) + lo;
     const int a0 = L::addr(c, base);
     uint32_t w[NP];
-    if (D > 1) {
+    w[0] = 0;
 #pragma unroll
-      for (int m = 1; m < NP; ++m) w[m] = tw[lo + m * D];
-    } else {
-#pragma unroll
-      for (int m = 2; m < NP; ++m) w[m] = tw[m];     // tw[1] == 1: handled by dif1/dit1
-    }
+    for (int m = 1; m < NP; ++m) w[m] = tw[lo + m * D];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       uint32_t x[NP];
 #pragma unroll
       for (int q = 0; q < NP; ++q) x[q] = s[v][a0 + L::padj(q * D)];
-      if constexpr (!INV) {
-        if constexpr (R == 3) {
-          r8_dif<LAZY, D == 1>(x, w, M);
-        } else if constexpr (R == 2) {
-          M.dif(x[0], x[2], w[2]); M.dif(x[1], x[3], w[3]);
-          if (D > 1) { M.dif(x[0], x[1], w[1]); M.dif(x[2], x[3], w[1]); }
-          else { M.dif1(x[0], x[1]); M.dif1(x[2], x[3]); }
-        } else {
-          if (D > 1) M.dif(x[0], x[1], w[1]); else M.dif1(x[0], x[1]);
-        }
+      if constexpr (R == 3) {
+        if constexpr (!INV) r8_dif<H, D == 1>(x, w, M); else r8_dit<H, D == 1>(x, w, M);
+      } else if constexpr (R == 2) {
+        r4_unit<H, D == 1, INV>(x, w, M);
       } else {
-        if constexpr (R == 3) {
-          r8_dit<LAZY, D == 1>(x, w, M);
-        } else if constexpr (R == 2) {
-          if (D > 1) { M.dit(x[0], x[1], w[1]); M.dit(x[2], x[3], w[1]); }
-          else { M.dit1(x[0], x[1]); M.dit1(x[2], x[3]); }
-          M.dit(x[0], x[2], w[2]); M.dit(x[1], x[3], w[3]);
-        } else {
-          if (D > 1) M.dit(x[0], x[1], w[1]); else M.dit1(x[0], x[1]);
-        }
+        r2_unit<H, D == 1, INV>(x, w, M);
       }
 #pragma unroll
       for (int q = 0; q < NP; ++q) s[v][a0 + L::padj(q * D)] = x[q];
@@ -189,28 +260,28 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
 }
 
 // Forward (DIF) rounds: largest distance first.  REM = log2 of the sub-transform still to do.
-template <class L, int REM, bool LAZY, int NV>
-__device__ __forceinline__ void dif_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Mod<LAZY> &M) {
+template <class L, int REM, int H, int NV>
+__device__ __forceinline__ void dif_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   if constexpr (REM >= 3) {
-    ntt_round<L, 3, REM - 3, false, LAZY, NV>(s, tw, M);
-    if constexpr (REM > 3) { __syncthreads(); dif_rounds<L, REM - 3, LAZY, NV>(s, tw, M); }
+    ntt_round<L, 3, REM - 3, false, H, NV>(s, tw, M);
+    if constexpr (REM > 3) { __syncthreads(); dif_rounds<L, REM - 3, H, NV>(s, tw, M); }
   } else if constexpr (REM == 2) {
-    ntt_round<L, 2, 0, false, LAZY, NV>(s, tw, M);
+    ntt_round<L, 2, 0, false, H, NV>(s, tw, M);
   } else if constexpr (REM == 1) {
-    ntt_round<L, 1, 0, false, LAZY, NV>(s, tw, M);
+    ntt_round<L, 1, 0, false, H, NV>(s, tw, M);
   }
 }
 
 // Inverse (DIT) rounds: the same partition walked from the smallest distance up.
-template <class L, int REM, bool LAZY, int NV>
-__device__ __forceinline__ void dit_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Mod<LAZY> &M) {
+template <class L, int REM, int H, int NV>
+__device__ __forceinline__ void dit_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   if constexpr (REM >= 3) {
-    if constexpr (REM > 3) { dit_rounds<L, REM - 3, LAZY, NV>(s, tw, M); __syncthreads(); }
-    ntt_round<L, 3, REM - 3, true, LAZY, NV>(s, tw, M);
+    if constexpr (REM > 3) { dit_rounds<L, REM - 3, H, NV>(s, tw, M); __syncthreads(); }
+    ntt_round<L, 3, REM - 3, true, H, NV>(s, tw, M);
   } else if constexpr (REM == 2) {
-    ntt_round<L, 2, 0, true, LAZY, NV>(s, tw, M);
+    ntt_round<L, 2, 0, true, H, NV>(s, tw, M);
   } else if constexpr (REM == 1) {
-    ntt_round<L, 1, 0, true, LAZY, NV>(s, tw, M);
+    ntt_round<L, 1, 0, true, H, NV>(s, tw, M);
   }
 }
 
@@ -235,8 +306,8 @@ template <class L>
 __device__ __forceinline__ void row_load(uint32_t *s, const uint32_t *in, long long row0, long long nrows) {
   constexpr int T = L::T;
   if constexpr (T >= 4) {
-    constexpr int V = L::NT * T / 4;
-    for (int v = threadIdx.x; v < V; v += WG) {
+    constexpr int NV4 = L::NT * T / 4;
+    for (int v = threadIdx.x; v < NV4; v += WG) {
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       uint4 x = make_uint4(0, 0, 0, 0);
       if (row0 + c < nrows) x = *reinterpret_cast<const uint4 *>(in + (row0 + c) * T + j);
@@ -250,29 +321,30 @@ __device__ __forceinline__ void row_load(uint32_t *s, const uint32_t *in, long l
   }
 }
 
-template <class L, bool LAZY>
+template <class L, int H>
 __device__ __forceinline__ void row_store(const uint32_t *s, uint32_t *out, long long row0, long long nrows,
-                                          const Mod<LAZY> &M, bool canon) {
+                                          const Arith<H> &M, bool canon) {
+  // stored values obey the forward or the inverse contract; KI >= KF covers both
   constexpr int T = L::T;
   if constexpr (T >= 4) {
-    constexpr int V = L::NT * T / 4;
-    for (int v = threadIdx.x; v < V; v += WG) {
+    constexpr int NV4 = L::NT * T / 4;
+    for (int v = threadIdx.x; v < NV4; v += WG) {
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       if (row0 + c < nrows) {
         uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c, j));
-        if (canon) { x.x = M.canon(x.x); x.y = M.canon(x.y); x.z = M.canon(x.z); x.w = M.canon(x.w); }
+        if (canon) { x.x = M.canon(M.inI(x.x)); x.y = M.canon(M.inI(x.y)); x.z = M.canon(M.inI(x.z)); x.w = M.canon(M.inI(x.w)); }
         *reinterpret_cast<uint4 *>(out + (row0 + c) * T + j) = x;
       }
     }
   } else {
     for (int v = threadIdx.x; v < L::NT * T; v += WG) {
       const int c = v / T, j = v % T;
-      if (row0 + c < nrows) { uint32_t x = s[L::addr(c, j)]; out[(row0 + c) * T + j] = canon ? M.canon(x) : x; }
+      if (row0 + c < nrows) { uint32_t x = s[L::addr(c, j)]; out[(row0 + c) * T + j] = canon ? M.canon(M.inI(x)) : x; }
     }
   }
 }
 
-template <int LOGT, int MODE, bool LAZY>
+template <int LOGT, int MODE, int H>
 __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
   using L = RowLayout<LOGT>;
   constexpr int T = L::T;
@@ -281,7 +353,7 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
   uint32_t *sa = lds, *sb = lds + (NVEC - 1) * L::WORDS;
   uint32_t *twf = lds + NVEC * L::WORDS;
   uint32_t *twi = twf + (MODE == ROW_MUL ? T : 0);
-  const Mod<LAZY> M(A.ctx);
+  const Arith<H> M(A.ctx);
 
   if (MODE != ROW_INV) for (int i = threadIdx.x; i < T; i += WG) twf[i] = A.tw_fwd[i];
   if (MODE != ROW_FWD) for (int i = threadIdx.x; i < T; i += WG) twi[i] = A.tw_inv[i];
@@ -293,32 +365,30 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
     __syncthreads();
     if (MODE == ROW_FWD) {
       uint32_t *const v[1] = {sa};
-      dif_rounds<L, LOGT, LAZY, 1>(v, twf, M);
+      dif_rounds<L, LOGT, H, 1>(v, twf, M);
     } else if (MODE == ROW_INV) {
       uint32_t *const v[1] = {sa};
-      dit_rounds<L, LOGT, LAZY, 1>(v, twi, M);
+      dit_rounds<L, LOGT, H, 1>(v, twi, M);
     } else {
       uint32_t *const v2[2] = {sa, sb};
-      dif_rounds<L, LOGT, LAZY, 2>(v2, twf, M);
+      dif_rounds<L, LOGT, H, 2>(v2, twf, M);
       __syncthreads();
       // pointwise product (plus the optional n^{-1} R^2 factor), into sa
       for (int i = threadIdx.x; i < L::NT * T; i += WG) {
         const int c = i >> LOGT, j = i & (T - 1);
         const int ad = L::addr(c, j);
-        uint32_t xa = sa[ad], xb = sb[ad];
-        uint32_t pr = M.mul(xa, xb);  // operands < 2p < 2^31 (lazy) or < p: product < 2^32 p
+        V<2> pr = M.mul2(M.inF(sa[ad]), M.inF(sb[ad]));
         if (A.scale) pr = M.mul(pr, A.scale);
-        sa[ad] = pr;
+        sa[ad] = pr.v;
       }
       __syncthreads();
       uint32_t *const v[1] = {sa};
-      dit_rounds<L, LOGT, LAZY, 1>(v, twi, M);
+      dit_rounds<L, LOGT, H, 1>(v, twi, M);
     }
     __syncthreads();
-    row_store<L, LAZY>(sa, A.out, row0, A.nrows, M, A.canon_out != 0);
+    row_store<L, H>(sa, A.out, row0, A.nrows, M, A.canon_out != 0);
   }
 }
-
 
 // ------------------------------------------------------------------------------------
 // Fused product on 512-point rows, one wavefront per row, no workgroup barrier.
@@ -332,12 +402,16 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
 // ------------------------------------------------------------------------------------
 constexpr int ROW9_PAD = 576;  // 512 + 8 pad words per 64
 
-template <bool LAZY>
-__global__ void __launch_bounds__(WG) row_mul9_kernel(RowArgs A) {
+#ifndef NTTX_ROW9_WAVES
+#define NTTX_ROW9_WAVES 4
+#endif
+template <int H>
+__global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[(WG / 64) * 2 * ROW9_PAD];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses stay in SGPRs
   uint32_t *sa = lds + wave * 2 * ROW9_PAD, *sb = sa + ROW9_PAD;
-  const Mod<LAZY> M(A.ctx);
+  const Arith<H> M(A.ctx);
   const int k8 = lane >> 3, m8 = lane & 7;
   const int o1 = lane;                       // R1: + 72 q
   const int o2 = 72 * k8 + m8;               // R2: + 8 j
@@ -353,31 +427,32 @@ __global__ void __launch_bounds__(WG) row_mul9_kernel(RowArgs A) {
 
   const long long nwaves = (long long)gridDim.x * (WG / 64);
   long long row = (long long)blockIdx.x * (WG / 64) + wave;
+  // na/nb: the row being loaded; round 1 runs in place on them, then they are refilled for the next row
   uint32_t na[8], nb[8];
   if (row < A.nrows) {
+    const uint32_t *pa = A.in0 + row * 512, *pb = A.in1 + row * 512;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { na[q] = A.in0[row * 512 + lane + 64 * q]; nb[q] = A.in1[row * 512 + lane + 64 * q]; }
+    for (int q = 0; q < 8; ++q) { na[q] = pa[lane + 64 * q]; nb[q] = pb[lane + 64 * q]; }
   }
   for (; row < A.nrows; row += nwaves) {
-    uint32_t a[8], b[8];
+    // forward round 1 (distances 256, 128, 64)
+    r8_dif<H, false>(na, wf1, M);
+    r8_dif<H, false>(nb, wf1, M);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { a[q] = na[q]; b[q] = nb[q]; }
+    for (int q = 0; q < 8; ++q) { sa[o1 + 72 * q] = na[q]; sb[o1 + 72 * q] = nb[q]; }
     const long long nrow = row + nwaves;
     if (nrow < A.nrows) {
+      const uint32_t *pa = A.in0 + nrow * 512, *pb = A.in1 + nrow * 512;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { na[q] = A.in0[nrow * 512 + lane + 64 * q]; nb[q] = A.in1[nrow * 512 + lane + 64 * q]; }
+      for (int q = 0; q < 8; ++q) { na[q] = pa[lane + 64 * q]; nb[q] = pb[lane + 64 * q]; }
     }
-    // forward round 1 (distances 256, 128, 64)
-    r8_dif<LAZY, false>(a, wf1, M);
-    r8_dif<LAZY, false>(b, wf1, M);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { sa[o1 + 72 * q] = a[q]; sb[o1 + 72 * q] = b[q]; }
     __builtin_amdgcn_wave_barrier();
+    uint32_t a[8], b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a[j] = sa[o2 + 8 * j]; b[j] = sb[o2 + 8 * j]; }
     // forward round 2 (32, 16, 8)
-    r8_dif<LAZY, false>(a, wf2, M);
-    r8_dif<LAZY, false>(b, wf2, M);
+    r8_dif<H, false>(a, wf2, M);
+    r8_dif<H, false>(b, wf2, M);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sa[o2 + 8 * j] = a[j]; sb[o2 + 8 * j] = b[j]; }
     __builtin_amdgcn_wave_barrier();
@@ -388,31 +463,38 @@ __global__ void __launch_bounds__(WG) row_mul9_kernel(RowArgs A) {
       b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
     }
     // forward round 3 (4, 2, 1), pointwise product, inverse round 1 (1, 2, 4): all on a lane's own 8 points
-    r8_dif<LAZY, true>(a, wf3, M);
-    r8_dif<LAZY, true>(b, wf3, M);
+    r8_dif<H, true>(a, wf3, M);
+    r8_dif<H, true>(b, wf3, M);
+    if (A.scale) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      uint32_t pr = M.mul(a[j], b[j]);
-      if (A.scale) pr = M.mul(pr, A.scale);
-      a[j] = pr;
+      for (int j = 0; j < 8; ++j) a[j] = M.mul(M.mul2(M.inF(a[j]), M.inF(b[j])), A.scale).v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = M.mul2(M.inF(a[j]), M.inF(b[j])).v;
     }
-    r8_dit<LAZY, true>(a, wi3, M);
+    r8_dit<H, true>(a, wi3, M);
     *reinterpret_cast<uint4 *>(sa + o3) = make_uint4(a[0], a[1], a[2], a[3]);
     *reinterpret_cast<uint4 *>(sa + o3 + 4) = make_uint4(a[4], a[5], a[6], a[7]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = sa[o2 + 8 * j];
     // inverse round 2 (8, 16, 32)
-    r8_dit<LAZY, false>(a, wi2, M);
+    r8_dit<H, false>(a, wi2, M);
 #pragma unroll
     for (int j = 0; j < 8; ++j) sa[o2 + 8 * j] = a[j];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = sa[o1 + 72 * q];
     // inverse round 3 (64, 128, 256)
-    r8_dit<LAZY, false>(a, wi1, M);
+    r8_dit<H, false>(a, wi1, M);
+    uint32_t *po = A.out + row * 512;
+    if (A.canon_out) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) A.out[row * 512 + lane + 64 * q] = A.canon_out ? M.canon(a[q]) : a[q];
+      for (int q = 0; q < 8; ++q) po[lane + 64 * q] = M.canon(M.inI(a[q]));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) po[lane + 64 * q] = a[q];
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -432,15 +514,12 @@ struct ColArgs {
   int logS;               // S = 2^logS >= columns per tile
   int canon_out;
   long long nblocks;      // batch * L / N
-#ifdef NTTX_DBG
-  int dbg;                // ablation: 1 = skip butterflies, 2 = skip global loads, 3 = skip global stores
-#endif
 };
 
 // Each thread moves PER = T*COLS/(4*NTHR) 16-byte pieces of a tile; LPR = COLS/4 lanes cover one
 // row segment.  The next tile's pieces are fetched into registers before the butterflies of the
 // current tile start, so HBM latency overlaps with compute inside one workgroup.
-template <int LOGT, bool INV, bool LAZY, int LOGC, int NTHR>
+template <int LOGT, bool INV, int H, int LOGC, int NTHR>
 __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
   using L = ColLayout<LOGT, LOGC, NTHR>;
   constexpr int T = L::T, COLS = L::COLS;
@@ -450,7 +529,7 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
   static_assert(PER >= 1 && PER * NTHR == T * LPR, "tile must be a whole number of pieces per thread");
   __shared__ __attribute__((aligned(16))) uint32_t lds[L::WORDS + T];
   uint32_t *s = lds, *tw = lds + L::WORDS;
-  const Mod<LAZY> M(A.ctx);
+  const Arith<H> M(A.ctx);
   const uint32_t *in = A.in[blockIdx.z];
   uint32_t *out = A.out[blockIdx.z];
   const int logS = A.logS;
@@ -483,7 +562,8 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
       const int j = j0 + k * RSTEP;
       if (INV) {
         const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
-        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y); x.z = M.mul(x.z, f.z); x.w = M.mul(x.w, f.w);
+        x.x = M.mul(M.inI(x.x), f.x).v; x.y = M.mul(M.inI(x.y), f.y).v;
+        x.z = M.mul(M.inI(x.z), f.z).v; x.w = M.mul(M.inI(x.w), f.w).v;
       }
       *reinterpret_cast<uint4 *>(s + L::addr(c4, j)) = x;
     }
@@ -495,8 +575,8 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
     }
     __syncthreads();
     uint32_t *const vec[1] = {s};
-    if (!INV) dif_rounds<L, LOGT, LAZY, 1>(vec, tw, M);
-    else dit_rounds<L, LOGT, LAZY, 1>(vec, tw, M);
+    if (!INV) dif_rounds<L, LOGT, H, 1>(vec, tw, M);
+    else dit_rounds<L, LOGT, H, 1>(vec, tw, M);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -504,9 +584,10 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
       uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c4, j));
       if (!INV) {
         const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
-        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y); x.z = M.mul(x.z, f.z); x.w = M.mul(x.w, f.w);
+        x.x = M.mul(M.inI(x.x), f.x).v; x.y = M.mul(M.inI(x.y), f.y).v;
+        x.z = M.mul(M.inI(x.z), f.z).v; x.w = M.mul(M.inI(x.w), f.w).v;
       }
-      if (A.canon_out) { x.x = M.canon(x.x); x.y = M.canon(x.y); x.z = M.canon(x.z); x.w = M.canon(x.w); }
+      if (A.canon_out) { x.x = M.canon(M.inI(x.x)); x.y = M.canon(M.inI(x.y)); x.z = M.canon(M.inI(x.z)); x.w = M.canon(M.inI(x.w)); }
       *reinterpret_cast<uint4 *>(out + gbase + ((long long)j << logS) + c4) = x;
     }
   }
