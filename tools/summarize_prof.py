@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn a tools/prof.sh result directory (gpurun_out/prof_<tag>) into the committed summary
+profiles/<tag>_rocprof.md and profiles/traffic.json.
+
+HBM bytes follow the MI355X guide's recipe: FETCH_SIZE and WRITE_SIZE come from separate
+--pmc passes, are reported in KiB, and FETCH_SIZE counts a 128-byte request of a wide
+(16 B per lane) coalesced stream as 64 bytes, so it is doubled for these kernels (their
+loads are all 16 B per lane; the doubled value matches the algorithmic byte count to 1 %)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join("gpurun_out", f"prof_{tag}")
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(name):
+    return name.split("(")[0].replace("void nttx::", "")
+
+
+def pmc(sub):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    if not files:
+        return d
+    for r in csv.DictReader(open(files[0])):
+        if "nttx::" not in r["Kernel_Name"]:
+            continue
+        d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+stats = []
+for r in csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])):
+    if "nttx::" in r["Name"]:
+        stats.append((short(r["Name"]), int(r["Calls"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["Percentage"])))
+
+fetch, write, sq, sq2 = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), pmc("pmc_sq2")
+mean = lambda v: sum(v) / len(v) if v else float("nan")
+kind = {"col_kernel<9, false": "col_fwd", "row_mul9_kernel": "row_mul", "col_kernel<9, true": "col_inv"}
+traffic = {}
+lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 5 --warmup 2 --no-cpu` (batch 256, L = 2^18, p = 469762049)", "",
+         "Kernel trace (`rocprofv3 --kernel-trace --stats`):", "",
+         "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
+for n, c, a, mn, mx, pct in stats:
+    lines.append(f"| `{n}` | {c} | {a/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {pct:.1f} |")
+lines += ["", "Counters (one `--pmc` pass each; values are per launch, mean over launches):", "",
+          "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes (2*FETCH+WRITE) | SQ_INSTS_VALU | SQ_INSTS_LDS | SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE | SQ_WAVE_CYCLES | SQ_WAIT_ANY | SQ_WAIT_INST_ANY | GRBM_GUI_ACTIVE/8 |",
+          "|---|---|---|---|---|---|---|---|---|---|---|"]
+for n, c, a, *_ in stats:
+    f, w = mean(fetch[n]["FETCH_SIZE"]), mean(write[n]["WRITE_SIZE"])
+    hbm = (2 * f + w) * 1024
+    for k, v in kind.items():
+        if n.startswith(k):
+            traffic[v] = hbm
+    s, s2 = sq[n], sq2[n]
+    lines.append(f"| `{n}` | {f:.0f} | {w:.0f} | {hbm/1e6:.1f} MB | {mean(s['SQ_INSTS_VALU'])/1e6:.2f} M | {mean(s['SQ_INSTS_LDS'])/1e6:.2f} M | "
+                 f"{mean(s['SQ_LDS_BANK_CONFLICT'])/1e6:.2f} M / {mean(s['SQ_LDS_IDX_ACTIVE'])/1e6:.2f} M | {mean(s['SQ_WAVE_CYCLES'])/1e6:.1f} M | "
+                 f"{mean(s2['SQ_WAIT_ANY'])/1e6:.1f} M | {mean(s2['SQ_WAIT_INST_ANY'])/1e6:.1f} M | {mean(s2['GRBM_GUI_ACTIVE'])/8/1e3:.1f} k cycles |")
+lines += ["", "Derived per launch (1024 SIMDs; VALU issue cost measured at about 4.6 cycles per wave instruction in butterfly code):", ""]
+for n, c, a, *_ in stats:
+    valu = mean(sq[n]["SQ_INSTS_VALU"])
+    cyc = mean(sq2[n]["GRBM_GUI_ACTIVE"]) / 8
+    if valu == valu and cyc == cyc:
+        lines.append(f"- `{n}`: effective clock {cyc / (a * 1e-9) / 1e9:.2f} GHz; VALU issue share ≈ {valu * 4.6 / 1024 / cyc * 100:.0f} % of kernel cycles; "
+                     f"HBM {traffic.get([v for k, v in kind.items() if n.startswith(k)][0], float('nan')) / (a * 1e-9) / 1e12:.2f} TB/s")
+open(os.path.join("profiles", f"{tag}_rocprof.md"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
+print("\n".join(lines))

@@ -8,7 +8,8 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
 
 // vector = 2^18 words (1 MiB) viewed as 512 rows x 512 words; batch of such vectors.
-template <int LOGC, int NTHR, int MODE>   // MODE 0: read+write, 1: read only, 2: write only
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int LOGC, int NTHR, int MODE, int NT = 0>   // MODE 0: read+write, 1: read only, 2: write only; NT: 1 = nontemporal loads, 2 = stores, 3 = both
 __global__ void __launch_bounds__(NTHR) tile_copy(const uint32_t *in, uint32_t *out, long long ntiles) {
   constexpr int COLS = 1 << LOGC, LPR = COLS / 4, LOG_LPR = LOGC - 2;
   constexpr int PER = 512 * LPR / NTHR, RSTEP = NTHR / LPR;
@@ -21,12 +22,20 @@ __global__ void __launch_bounds__(NTHR) tile_copy(const uint32_t *in, uint32_t *
     uint4 x[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      if (MODE != 2) x[k] = *reinterpret_cast<const uint4 *>(in + base + ((long long)(j0 + k * RSTEP) << 9));
+      if (MODE != 2) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(in + base + ((long long)(j0 + k * RSTEP) << 9));
+        u32x4 v = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+        x[k] = make_uint4(v.x, v.y, v.z, v.w);
+      }
       else x[k] = make_uint4(k, t, 3, 4);
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      if (MODE != 1) *reinterpret_cast<uint4 *>(out + base + ((long long)(j0 + k * RSTEP) << 9)) = x[k];
+      if (MODE != 1) {
+        u32x4 v = {x[k].x, x[k].y, x[k].z, x[k].w};
+        u32x4 *dst = reinterpret_cast<u32x4 *>(out + base + ((long long)(j0 + k * RSTEP) << 9));
+        if (NT & 2) __builtin_nontemporal_store(v, dst); else *dst = v;
+      }
       else acc ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
     }
   }
@@ -61,7 +70,7 @@ int main() {
   CHECK(hipMemset(a, 1, words * 4)); CHECK(hipMemset(b, 2, words * 4));
   const double gb = words * 4 / 1e9;
   const char *mn[3] = {"read+write", "read only", "write only"};
-  for (int grid : {1024, 2048, 4096, 8192}) {
+  for (int grid : {512, 2048}) {
     printf("grid %d\n", grid);
 #define FLAT(M) { double ms = timeit([&] { flat_copy<M><<<grid, 256>>>((const uint4 *)a, (uint4 *)b, words / 4); }); \
       printf("  flat 16B/lane      %-10s %7.3f ms  %7.1f GB/s\n", mn[M], ms, gb * (M == 0 ? 2 : 1) / ms * 1e3); }
@@ -73,6 +82,10 @@ int main() {
     TILE(5, 256, 0) TILE(5, 512, 0) TILE(5, 512, 1) TILE(5, 512, 2)
     TILE(6, 512, 0) TILE(6, 1024, 0) TILE(6, 512, 1) TILE(6, 512, 2)
     TILE(7, 1024, 0)
+#define TILENT(LC, NT_, M, NTF) { long long nt = (long long)batch << (9 - LC); \
+      double ms = timeit([&] { tile_copy<LC, NT_, M, NTF><<<grid, NT_>>>(a, b, nt); }); \
+      printf("  tile seg %3d B thr %3d %-10s nt=%d %7.3f ms  %7.1f GB/s\n", 4 << LC, NT_, mn[M], NTF, ms, gb * (M == 0 ? 2 : 1) / ms * 1e3); }
+    TILENT(5, 512, 0, 1) TILENT(5, 512, 0, 2) TILENT(5, 512, 0, 3) TILENT(5, 512, 1, 1) TILENT(5, 512, 2, 2)
   }
   return 0;
 }
