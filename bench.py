@@ -24,10 +24,11 @@ P = 469762049
 LOG_L = 18
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
 # algorithmic HBM bytes per multiplication, per kernel (u32 words of length L moved once):
-#   col_fwd reads a,b and writes both transformed copies  -> 4 L words
-#   row_mul reads both copies and writes the product rows -> 3 L words
-#   col_inv reads and writes the product                  -> 2 L words
-KERNEL_WORDS = {"col_fwd": 4, "row_mul": 3, "col_inv": 2}
+#   col_fwd reads the n = L/2 coefficients of a and b (their zero padding is never read) and
+#           writes both transformed copies                  -> 1 + 2 = 3 L words
+#   row_mul reads both copies and writes the product rows   -> 3 L words
+#   col_inv reads and writes the product                    -> 2 L words
+KERNEL_WORDS = {"col_fwd": 3, "row_mul": 3, "col_inv": 2}
 MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per multiplication
 
 
@@ -98,7 +99,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ntt_amd.dev_cyclic_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), L, P, B, stream)
+        ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P, B, stream)
 
     for _ in range(args.warmup):
         step()
@@ -178,7 +179,7 @@ def main():
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()},
             "pipeline_model": {"bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "achieved_GBs_per_gpu": model_gbs,
                                "frac_of_peak": model_gbs / HBM_PEAK_GBS,
-                               "bytes_per_mult_moved": 36 * L},
+                               "bytes_per_mult_moved": 32 * L},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n, P)

@@ -81,6 +81,13 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
 int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch,
                                  void *stream);
 
+/* Linear product of n-coefficient polynomials held zero-padded in [batch][len] arrays, len the
+ * smallest power of two >= 2n (the padding of main.cc:278-281): d_c[b][0..2n-2] = a*b mod p, the
+ * rest of d_c[b] is zero.  Words of d_a, d_b at index >= n must be zero and are not read on lengths
+ * that take more than one pass (half the input traffic of the cyclic call).  Asynchronous on `stream`. */
+int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch,
+                               void *stream);
+
 /* d_ab[b][0..2n-2] = a*b mod p through the 4-prime CRT path; d_a, d_b are [batch][n] u64,
  * d_ab is [batch][2n-1] u64, all device memory.  Asynchronous on `stream`. */
 int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch,

@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     cyclic_multiply,
     dev_crt_multiply_u64,
     dev_cyclic_multiply_u32,
+    dev_poly_multiply_u32,
     dev_ntt_u32,
     exported_symbols,
     init,
@@ -37,7 +38,7 @@ from . import harness  # noqa: F401
 
 __all__ = [
     "NttxError", "CRT_PRIMES", "PATH_CRT4", "PATH_DIRECT32", "crt_combine", "cyclic_multiply",
-    "dev_crt_multiply_u64", "dev_cyclic_multiply_u32", "dev_ntt_u32", "exported_symbols", "init", "lib", "ntt",
+    "dev_crt_multiply_u64", "dev_cyclic_multiply_u32", "dev_poly_multiply_u32", "dev_ntt_u32", "exported_symbols", "init", "lib", "ntt",
     "path_for", "plan_info", "poly_multiply", "poly_multiply_batch", "poly_multiply_crt", "profile_enable", "profile_read", "profile_reset", "KERNEL_KINDS",
     "reserve", "shutdown",
     "harness",

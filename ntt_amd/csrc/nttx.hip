@@ -262,14 +262,14 @@ static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream
 
 // Column tile shape: 32 columns (full 128-byte lines) with 512 threads where the tile fits LDS
 // comfortably, 16 columns with 256 threads for the longest column passes.
-template <bool INV, int H>
+template <bool INV, int H, bool ZHI>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
   const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
   static const int capc = env_int("NTTX_GRID_COL", 2048);
   const int grid = grid_for(tiles, std::max(1, capc / nvec));
 #define NTTX_COL_CASE(K, LC, NT) \
-    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
   switch (logT * 2 + wide) {
     case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
     case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
@@ -282,14 +282,17 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-template <bool INV>
+template <bool INV, bool ZHI>
 static int launch_col_i(int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  return h == 9 ? launch_col_t<INV, 9>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4>(logT, A, nvec, st)
-                                                                   : launch_col_t<INV, 2>(logT, A, nvec, st);
+  return h == 9 ? launch_col_t<INV, 9, ZHI>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4, ZHI>(logT, A, nvec, st)
+                                                                        : launch_col_t<INV, 2, ZHI>(logT, A, nvec, st);
 }
+// A.nvalid > 0 selects the zero-padded-half forward variant (needs nvalid <= N/2)
 static int launch_col_raw(bool inv, int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
   if (logT < kMinColLog || A.logS < 4) return fail(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
-  return inv ? launch_col_i<true>(h, logT, A, nvec, st) : launch_col_i<false>(h, logT, A, nvec, st);
+  if (inv) return launch_col_i<true, false>(h, logT, A, nvec, st);
+  if (A.nvalid > 0) return launch_col_i<false, true>(h, logT, A, nvec, st);
+  return launch_col_i<false, false>(h, logT, A, nvec, st);
 }
 
 static int launch_row(Context *cx, int mode, int h, int logT, const RowArgs &A, hipStream_t st) {
@@ -320,8 +323,10 @@ static int chunk_for(int logL, int batch) {
 }
 
 // c = cyclic product of a and b, all [batch][2^logL] u32 on the device
+// nvalid > 0: only the first nvalid words of every input vector are read, the rest counts as zero
+// (the zero padding of a linear product, main.cc:280-281); needs nvalid <= len/2 to take effect.
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
-                               hipStream_t st) {
+                               hipStream_t st, long long nvalid = 0) {
   const long long len = 1ll << pl->logL;
   if (pl->npass == 1) {
     RowArgs R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
@@ -359,6 +364,7 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
       ColArgs C{}; C.in[0] = lv == 0 ? ca : wa; C.in[1] = lv == 0 ? cb : wb; C.out[0] = wa; C.out[1] = wb;
       C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
       C.nblocks = ((long long)nb << pl->logL) >> logN;
+      C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
       if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, gs)) return rc;
       logN = C.logS;
     }
@@ -466,7 +472,7 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
     const uint32_t *a = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
     const uint32_t *b = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
     uint32_t *c = cx->pc.as<uint32_t>() + (size_t)k * batch * len;
-    if (int rc = dev_cyclic_multiply(cx, pl[k], a, b, c, batch, st)) return rc;
+    if (int rc = dev_cyclic_multiply(cx, pl[k], a, b, c, batch, st, n)) return rc;
     A.res[k] = c;
   }
   A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len; A.total = (long long)batch * A.nout;
@@ -584,6 +590,14 @@ int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, in
   return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch, (hipStream_t)stream);
 }
 
+int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_c || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
+  Plan *pl;
+  if (int rc = get_plan(cx, p, log2_ceil_len(n), false, &pl)) return rc;
+  return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch, (hipStream_t)stream, n);
+}
+
 int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch, void *stream) {
   NTTX_ENTER();
   if (!d_a || !d_b || !d_ab || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
@@ -681,7 +695,7 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   hipLaunchKernelGGL(pad_kernel, dim3(ew_grid(total)), dim3(256), 0, 0, cx->in_a.as<uint32_t>(), cx->pa.as<uint32_t>(), p, n, (int)len, total);
   hipLaunchKernelGGL(pad_kernel, dim3(ew_grid(total)), dim3(256), 0, 0, cx->in_b.as<uint32_t>(), cx->pb.as<uint32_t>(), p, n, (int)len, total);
   HIPCHK(hipGetLastError());
-  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), batch, nullptr)) return rc;
+  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), batch, nullptr, n)) return rc;
   const long long tout = (long long)batch * nout;
   hipLaunchKernelGGL((unpad_kernel<uint32_t>), dim3(ew_grid(tout)), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len, tout);
   HIPCHK(hipGetLastError());
@@ -748,7 +762,7 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
     hipLaunchKernelGGL(split_kernel, dim3(ew_grid(S.total)), dim3(256), 0, 0, S);
   }
   HIPCHK(hipGetLastError());
-  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr)) return rc;
+  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr, n)) return rc;
   hipLaunchKernelGGL((unpad_kernel<uint64_t>), dim3(ew_grid(nout)), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len, (long long)nout);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));

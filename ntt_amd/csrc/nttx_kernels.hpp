@@ -104,14 +104,20 @@ struct Arith {
 // (w[1], w[2], w[4]) and their products are skipped.  x[] holds values below KF*p (forward) or
 // KI*p (inverse) on entry and on exit.
 // ------------------------------------------------------------------------------------
-template <int H, bool UNIT_D1>
+// ZHI: the upper four inputs are known to be zero (the zero-padded half of a linear product), so
+// the distance-4D stage degenerates to (a, a*w) and x[4..7] are not read.
+template <int H, bool UNIT_D1, bool ZHI = false>
 __device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8], const Arith<H> &M) {
   const V<Arith<H>::KF> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
   // distance 4D
-  const auto p04 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i4); else return M.dif(i0, i4, w[4]); }();
-  const auto p15 = M.dif(i1, i5, w[5]);
-  const auto p26 = M.dif(i2, i6, w[6]);
-  const auto p37 = M.dif(i3, i7, w[7]);
+  const auto p04 = [&] {
+    if constexpr (ZHI) return mkpair(i0, M.mul(i0, w[4]));
+    else if constexpr (UNIT_D1) return M.bf1(i0, i4);
+    else return M.dif(i0, i4, w[4]);
+  }();
+  const auto p15 = [&] { if constexpr (ZHI) return mkpair(i1, M.mul(i1, w[5])); else return M.dif(i1, i5, w[5]); }();
+  const auto p26 = [&] { if constexpr (ZHI) return mkpair(i2, M.mul(i2, w[6])); else return M.dif(i2, i6, w[6]); }();
+  const auto p37 = [&] { if constexpr (ZHI) return mkpair(i3, M.mul(i3, w[7])); else return M.dif(i3, i7, w[7]); }();
   // distance 2D
   const auto q02 = [&] { if constexpr (UNIT_D1) return M.bf1(p04.a, p26.a); else return M.dif(p04.a, p26.a, w[2]); }();
   const auto q13 = M.dif(p15.a, p37.a, w[3]);
@@ -225,7 +231,7 @@ struct ColLayout {
 // the tile, for NV vectors that share twiddles (a and b of a product).
 // tw is the stage-major table: tw[h + j] = g^(j*T/(2h)), j < h, Montgomery form.
 // ------------------------------------------------------------------------------------
-template <class L, int R, int LOGD, bool INV, int H, int NV>
+template <class L, int R, int LOGD, bool INV, int H, int NV, bool ZHI = false>
 __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   constexpr int D = 1 << LOGD;
   constexpr int LOG_UNITS = L::LOGT - R;  // log2(units per transform)
@@ -245,9 +251,9 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
     for (int v = 0; v < NV; ++v) {
       uint32_t x[NP];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) x[q] = s[v][a0 + L::padj(q * D)];
+      for (int q = 0; q < NP; ++q) x[q] = (ZHI && q >= NP / 2) ? 0u : s[v][a0 + L::padj(q * D)];
       if constexpr (R == 3) {
-        if constexpr (!INV) r8_dif<H, D == 1>(x, w, M); else r8_dit<H, D == 1>(x, w, M);
+        if constexpr (!INV) r8_dif<H, D == 1, ZHI>(x, w, M); else r8_dit<H, D == 1>(x, w, M);
       } else if constexpr (R == 2) {
         r4_unit<H, D == 1, INV>(x, w, M);
       } else {
@@ -260,10 +266,10 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
 }
 
 // Forward (DIF) rounds: largest distance first.  REM = log2 of the sub-transform still to do.
-template <class L, int REM, int H, int NV>
+template <class L, int REM, int H, int NV, bool ZTOP = false>
 __device__ __forceinline__ void dif_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   if constexpr (REM >= 3) {
-    ntt_round<L, 3, REM - 3, false, H, NV>(s, tw, M);
+    ntt_round<L, 3, REM - 3, false, H, NV, ZTOP>(s, tw, M);   // ZTOP: upper half of the transform input is zero
     if constexpr (REM > 3) { __syncthreads(); dif_rounds<L, REM - 3, H, NV>(s, tw, M); }
   } else if constexpr (REM == 2) {
     ntt_round<L, 2, 0, false, H, NV>(s, tw, M);
@@ -514,19 +520,24 @@ struct ColArgs {
   int logS;               // S = 2^logS >= columns per tile
   int canon_out;
   long long nblocks;      // batch * L / N
+  long long nvalid;       // ZHI kernels: words of each block that hold data; the rest reads as zero
 };
 
 // Each thread moves PER = T*COLS/(4*NTHR) 16-byte pieces of a tile; LPR = COLS/4 lanes cover one
 // row segment.  The next tile's pieces are fetched into registers before the butterflies of the
 // current tile start, so HBM latency overlaps with compute inside one workgroup.
-template <int LOGT, bool INV, int H, int LOGC, int NTHR>
+// ZHI (forward only): each block is a zero-padded vector whose first nvalid <= N/2 words hold data.
+// Rows from T/2 on are never read (half the input traffic) and the first butterfly stage degenerates.
+template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false>
 __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
   using L = ColLayout<LOGT, LOGC, NTHR>;
   constexpr int T = L::T, COLS = L::COLS;
   constexpr int LPR = COLS / 4, LOG_LPR = LOGC - 2;
   constexpr int PER = (T * LPR) / NTHR;
   constexpr int RSTEP = NTHR / LPR;              // rows covered by one piece index
+  constexpr int PERL = ZHI ? (PER + 1) / 2 : PER;  // pieces actually loaded (rows below T/2)
   static_assert(PER >= 1 && PER * NTHR == T * LPR, "tile must be a whole number of pieces per thread");
+  static_assert(!ZHI || (!INV && (PER % 2 == 0 || PER == 1)), "zero-half variant is forward only");
   __shared__ __attribute__((aligned(16))) uint32_t lds[L::WORDS + T];
   uint32_t *s = lds, *tw = lds + L::WORDS;
   const Arith<H> M(A.ctx);
@@ -546,18 +557,33 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
   };
   auto fs_base = [&](long long t) -> long long { return (t & ((1ll << log_tpb) - 1)) << LOGC; };
 
-  uint4 nx[PER];
+  // one 16-byte piece of the tile at row j; ZHI masks words at or beyond nvalid of the block
+  auto load_piece = [&](long long base, long long t_, int j) -> uint4 {
+    if constexpr (!ZHI) {
+      return *reinterpret_cast<const uint4 *>(in + base + ((long long)j << logS) + c4);
+    } else {
+      const long long ct = t_ & ((1ll << log_tpb) - 1);
+      const long long w0 = ((long long)j << logS) + (ct << LOGC) + c4;   // word index inside the block
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (j < T / 2 && w0 < A.nvalid) {
+        x = *reinterpret_cast<const uint4 *>(in + base + ((long long)j << logS) + c4);
+        if (w0 + 3 >= A.nvalid) { if (w0 + 1 >= A.nvalid) x.y = 0; if (w0 + 2 >= A.nvalid) x.z = 0; x.w = 0; }
+      }
+      return x;
+    }
+  };
+  uint4 nx[PERL];
   long long t = blockIdx.x;
   if (t < ntiles) {
-    const uint32_t *src = in + tile_base(t) + c4;
+    const long long base = tile_base(t);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) nx[k] = *reinterpret_cast<const uint4 *>(src + ((long long)(j0 + k * RSTEP) << logS));
+    for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, t, j0 + k * RSTEP);
   }
   for (; t < ntiles; t += gridDim.x) {
     const long long gbase = tile_base(t), fbase = fs_base(t);
     __syncthreads();   // previous tile's LDS reads are done
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
+    for (int k = 0; k < PERL; ++k) {
       uint4 x = nx[k];
       const int j = j0 + k * RSTEP;
       if (INV) {
@@ -569,13 +595,13 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
     }
     const long long tn = t + gridDim.x;
     if (tn < ntiles) {
-      const uint32_t *src = in + tile_base(tn) + c4;
+      const long long base = tile_base(tn);
 #pragma unroll
-      for (int k = 0; k < PER; ++k) nx[k] = *reinterpret_cast<const uint4 *>(src + ((long long)(j0 + k * RSTEP) << logS));
+      for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, tn, j0 + k * RSTEP);
     }
     __syncthreads();
     uint32_t *const vec[1] = {s};
-    if (!INV) dif_rounds<L, LOGT, H, 1>(vec, tw, M);
+    if constexpr (!INV) dif_rounds<L, LOGT, H, 1, ZHI>(vec, tw, M);
     else dit_rounds<L, LOGT, H, 1>(vec, tw, M);
     __syncthreads();
 #pragma unroll

@@ -257,3 +257,27 @@ def test_cpp_harness_binary(oracle, tmp_path):
     for i in range(5):
         got = np.loadtxt(tmp_path / "files" / f"{i}.out", dtype=np.uint64, ndmin=1)
         assert np.array_equal(got, wants[i])
+
+
+@pytest.mark.parametrize("n", (131072, 100003, 70000, 65537))
+def test_device_linear_product_skips_padding(nttx, oracle, n):
+    """nttx_dev_poly_multiply_u32: zero-padded device arrays, padding never read; ragged n."""
+    import torch
+    p, batch = 469762049, 3
+    L = 1
+    while L < 2 * n:
+        L *= 2
+    a = np.zeros((batch, L), np.uint32)
+    b = np.zeros((batch, L), np.uint32)
+    a[:, :n] = rand(oracle, n * batch, 81, p).reshape(batch, n)
+    b[:, :n] = rand(oracle, n * batch, 82, p).reshape(batch, n)
+    da = torch.from_numpy(a.view(np.int32)).cuda()
+    db = torch.from_numpy(b.view(np.int32)).cuda()
+    dc = torch.full_like(da, 7)
+    nttx.dev_poly_multiply_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), n, p, batch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c = dc.cpu().numpy().view(np.uint32)
+    for i in range(batch):
+        want = oracle.poly_multiply_crt(a[i, :n].astype(np.uint64), b[i, :n].astype(np.uint64), p)
+        assert np.array_equal(c[i, :2 * n - 1].astype(np.uint64), want), (n, i)
+        assert not c[i, 2 * n - 1:].any()
