@@ -233,7 +233,8 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
   if (MODE == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
     const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
     static const int cap9 = env_int("NTTX_GRID_ROW", 256 * 8);
-    hipLaunchKernelGGL(row_mul9_kernel<H>, dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    else hipLaunchKernelGGL((row_mul9_kernel<H, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -264,17 +265,18 @@ static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream
 // comfortably, 16 columns with 256 threads for the longest column passes.
 template <bool INV, int H, bool ZHI>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
+  static const int narrow = env_int("NTTX_COL16", 0);
+  const int wide = (logT <= 9 && A.logS >= 5 && !narrow) ? 1 : 0;
   const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
   static const int capc = env_int("NTTX_GRID_COL", 2048);
-  const int grid = grid_for(tiles, std::max(1, capc / nvec));
+  const int grid = (grid_for(tiles, std::max(1, capc / nvec)) + 15) / 16 * 16 <= tiles ? (grid_for(tiles, std::max(1, capc / nvec)) + 15) / 16 * 16 : grid_for(tiles, std::max(1, capc / nvec));
 #define NTTX_COL_CASE(K, LC, NT) \
     hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
   switch (logT * 2 + wide) {
     case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
     case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
     case 16: NTTX_COL_CASE(8, 4, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
-    case 18: NTTX_COL_CASE(9, 4, 256)   case 19: NTTX_COL_CASE(9, 5, 512)
+    case 18: NTTX_COL_CASE(9, 4, 256)   case 19: NTTX_COL_CASE(9, 5, 1024)
     case 20: NTTX_COL_CASE(10, 4, 256)
     default: return fail(NTTX_ERANGE, "column pass of 2^%d points unsupported", logT);
   }

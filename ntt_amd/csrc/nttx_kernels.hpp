@@ -44,11 +44,15 @@ __device__ __forceinline__ Pair<A, B> mkpair(A a, B b) { return Pair<A, B>{a, b}
 
 template <int H>
 struct Arith {
-  // Bounds kept by values that cross an LDS exchange or a kernel boundary, per direction.  Chosen
-  // by counting the conditional subtractions a radix-8 unit needs under each contract (forward
-  // units want small inputs because sums add bounds; inverse units only ever add 2p per stage).
-  static constexpr int KF = (H >= 9) ? 4 : 2;   // forward (decimation-in-frequency) passes
-  static constexpr int KI = (H >= 4) ? 4 : 2;   // inverse (decimation-in-time) passes
+  // Bounds kept by values that cross an LDS exchange between rounds, per direction.  Chosen by
+  // counting the conditional subtractions a radix-8 unit needs under each contract (forward units
+  // want small inputs because sums add bounds; inverse units only ever add 2p per stage).
+  static constexpr int KF = 2;                                   // forward (decimation-in-frequency) rounds
+  static constexpr int KI = (H >= 9) ? 8 : (H >= 4) ? 4 : 2;     // inverse (decimation-in-time) rounds
+  // bound left on the two factors of a pointwise product (KP*KP <= H where possible)
+  static constexpr int KP = (H >= 9) ? 3 : 2;
+  // a value about to be multiplied by a Montgomery constant needs no reduction at all
+  static constexpr int KANY = H;
   uint32_t p, npinv;
   __device__ __forceinline__ Arith(const PrimeCtx &c) : p(c.p), npinv(c.npinv) {}
   template <int C>
@@ -91,24 +95,21 @@ struct Arith {
   __device__ __forceinline__ auto dit(V<KA> a, V<KB> b, uint32_t w) const { return bf1(a, mul(b, w)); }
   template <int K>
   __device__ __forceinline__ uint32_t canon(V<K> x) const { return reduce<1>(x).v; }
-  template <bool INV, int K>
-  __device__ __forceinline__ uint32_t lazy(V<K> x) const { return reduce<(INV ? KI : KF)>(x).v; }
-  // a value read back under the forward / inverse contract
-  __device__ __forceinline__ V<KF> inF(uint32_t x) const { return V<KF>{x}; }
-  __device__ __forceinline__ V<KI> inI(uint32_t x) const { return V<KI>{x}; }
+  template <int KOUT, int K>
+  __device__ __forceinline__ uint32_t out(V<K> x) const { return reduce<KOUT>(x).v; }
 };
 
 // ------------------------------------------------------------------------------------
 // Radix-8 / 4 / 2 units on registers: stages at point distances 4D, 2D, D.
 // w[m] = tw[lo + m*D]; UNIT_D1 marks D == 1 where the twiddles of index 0 equal 1
-// (w[1], w[2], w[4]) and their products are skipped.  x[] holds values below KF*p (forward) or
-// KI*p (inverse) on entry and on exit.
+// (w[1], w[2], w[4]) and their products are skipped.  x[] holds values below KIN*p on entry and
+// below KOUT*p on exit (KOUT = KANY: no reduction, the consumer multiplies by a constant).
 // ------------------------------------------------------------------------------------
 // ZHI: the upper four inputs are known to be zero (the zero-padded half of a linear product), so
 // the distance-4D stage degenerates to (a, a*w) and x[4..7] are not read.
-template <int H, bool UNIT_D1, bool ZHI = false>
+template <int H, bool UNIT_D1, bool ZHI = false, int KIN = Arith<H>::KF, int KOUT = Arith<H>::KF>
 __device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8], const Arith<H> &M) {
-  const V<Arith<H>::KF> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
+  const V<KIN> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
   // distance 4D
   const auto p04 = [&] {
     if constexpr (ZHI) return mkpair(i0, M.mul(i0, w[4]));
@@ -128,13 +129,13 @@ __device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8],
   const auto r23 = [&] { if constexpr (UNIT_D1) return M.bf1(q02.b, q13.b); else return M.dif(q02.b, q13.b, w[1]); }();
   const auto r45 = [&] { if constexpr (UNIT_D1) return M.bf1(q46.a, q57.a); else return M.dif(q46.a, q57.a, w[1]); }();
   const auto r67 = [&] { if constexpr (UNIT_D1) return M.bf1(q46.b, q57.b); else return M.dif(q46.b, q57.b, w[1]); }();
-  x[0] = M.template lazy<false>(r01.a); x[1] = M.template lazy<false>(r01.b); x[2] = M.template lazy<false>(r23.a); x[3] = M.template lazy<false>(r23.b);
-  x[4] = M.template lazy<false>(r45.a); x[5] = M.template lazy<false>(r45.b); x[6] = M.template lazy<false>(r67.a); x[7] = M.template lazy<false>(r67.b);
+  x[0] = M.template out<KOUT>(r01.a); x[1] = M.template out<KOUT>(r01.b); x[2] = M.template out<KOUT>(r23.a); x[3] = M.template out<KOUT>(r23.b);
+  x[4] = M.template out<KOUT>(r45.a); x[5] = M.template out<KOUT>(r45.b); x[6] = M.template out<KOUT>(r67.a); x[7] = M.template out<KOUT>(r67.b);
 }
 
-template <int H, bool UNIT_D1>
+template <int H, bool UNIT_D1, int KIN = Arith<H>::KI, int KOUT = Arith<H>::KI>
 __device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8], const Arith<H> &M) {
-  const V<Arith<H>::KI> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
+  const V<KIN> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
   // distance D
   const auto p01 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i1); else return M.dit(i0, i1, w[1]); }();
   const auto p23 = [&] { if constexpr (UNIT_D1) return M.bf1(i2, i3); else return M.dit(i2, i3, w[1]); }();
@@ -150,40 +151,40 @@ __device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8],
   const auto r15 = M.dit(q13.a, q57.a, w[5]);
   const auto r26 = M.dit(q02.b, q46.b, w[6]);
   const auto r37 = M.dit(q13.b, q57.b, w[7]);
-  x[0] = M.template lazy<true>(r04.a); x[4] = M.template lazy<true>(r04.b); x[1] = M.template lazy<true>(r15.a); x[5] = M.template lazy<true>(r15.b);
-  x[2] = M.template lazy<true>(r26.a); x[6] = M.template lazy<true>(r26.b); x[3] = M.template lazy<true>(r37.a); x[7] = M.template lazy<true>(r37.b);
+  x[0] = M.template out<KOUT>(r04.a); x[4] = M.template out<KOUT>(r04.b); x[1] = M.template out<KOUT>(r15.a); x[5] = M.template out<KOUT>(r15.b);
+  x[2] = M.template out<KOUT>(r26.a); x[6] = M.template out<KOUT>(r26.b); x[3] = M.template out<KOUT>(r37.a); x[7] = M.template out<KOUT>(r37.b);
 }
 
-template <int H, bool UNIT_D1, bool INV>
+template <int H, bool UNIT_D1, bool INV, int KIN, int KOUT>
 __device__ __forceinline__ void r4_unit(uint32_t (&x)[4], const uint32_t (&w)[4], const Arith<H> &M) {
-  const V<(INV ? Arith<H>::KI : Arith<H>::KF)> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]};
+  const V<KIN> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]};
   if constexpr (!INV) {
     const auto p02 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i2); else return M.dif(i0, i2, w[2]); }();
     const auto p13 = M.dif(i1, i3, w[3]);
     const auto q01 = [&] { if constexpr (UNIT_D1) return M.bf1(p02.a, p13.a); else return M.dif(p02.a, p13.a, w[1]); }();
     const auto q23 = [&] { if constexpr (UNIT_D1) return M.bf1(p02.b, p13.b); else return M.dif(p02.b, p13.b, w[1]); }();
-    x[0] = M.template lazy<INV>(q01.a); x[1] = M.template lazy<INV>(q01.b); x[2] = M.template lazy<INV>(q23.a); x[3] = M.template lazy<INV>(q23.b);
+    x[0] = M.template out<KOUT>(q01.a); x[1] = M.template out<KOUT>(q01.b); x[2] = M.template out<KOUT>(q23.a); x[3] = M.template out<KOUT>(q23.b);
   } else {
     const auto p01 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i1); else return M.dit(i0, i1, w[1]); }();
     const auto p23 = [&] { if constexpr (UNIT_D1) return M.bf1(i2, i3); else return M.dit(i2, i3, w[1]); }();
     const auto q02 = [&] { if constexpr (UNIT_D1) return M.bf1(p01.a, p23.a); else return M.dit(p01.a, p23.a, w[2]); }();
     const auto q13 = M.dit(p01.b, p23.b, w[3]);
-    x[0] = M.template lazy<INV>(q02.a); x[2] = M.template lazy<INV>(q02.b); x[1] = M.template lazy<INV>(q13.a); x[3] = M.template lazy<INV>(q13.b);
+    x[0] = M.template out<KOUT>(q02.a); x[2] = M.template out<KOUT>(q02.b); x[1] = M.template out<KOUT>(q13.a); x[3] = M.template out<KOUT>(q13.b);
   }
 }
 
-template <int H, bool UNIT_D1, bool INV>
+template <int H, bool UNIT_D1, bool INV, int KIN, int KOUT>
 __device__ __forceinline__ void r2_unit(uint32_t (&x)[2], const uint32_t (&w)[2], const Arith<H> &M) {
-  const V<(INV ? Arith<H>::KI : Arith<H>::KF)> i0{x[0]}, i1{x[1]};
+  const V<KIN> i0{x[0]}, i1{x[1]};
   if constexpr (UNIT_D1) {
     const auto r = M.bf1(i0, i1);
-    x[0] = M.template lazy<INV>(r.a); x[1] = M.template lazy<INV>(r.b);
+    x[0] = M.template out<KOUT>(r.a); x[1] = M.template out<KOUT>(r.b);
   } else if constexpr (!INV) {
     const auto r = M.dif(i0, i1, w[1]);
-    x[0] = M.template lazy<INV>(r.a); x[1] = M.template lazy<INV>(r.b);
+    x[0] = M.template out<KOUT>(r.a); x[1] = M.template out<KOUT>(r.b);
   } else {
     const auto r = M.dit(i0, i1, w[1]);
-    x[0] = M.template lazy<INV>(r.a); x[1] = M.template lazy<INV>(r.b);
+    x[0] = M.template out<KOUT>(r.a); x[1] = M.template out<KOUT>(r.b);
   }
 }
 
@@ -231,7 +232,7 @@ struct ColLayout {
 // the tile, for NV vectors that share twiddles (a and b of a product).
 // tw is the stage-major table: tw[h + j] = g^(j*T/(2h)), j < h, Montgomery form.
 // ------------------------------------------------------------------------------------
-template <class L, int R, int LOGD, bool INV, int H, int NV, bool ZHI = false>
+template <class L, int R, int LOGD, bool INV, int H, int NV, bool ZHI, int KIN, int KOUT>
 __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   constexpr int D = 1 << LOGD;
   constexpr int LOG_UNITS = L::LOGT - R;  // log2(units per transform)
@@ -253,11 +254,11 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
 #pragma unroll
       for (int q = 0; q < NP; ++q) x[q] = (ZHI && q >= NP / 2) ? 0u : s[v][a0 + L::padj(q * D)];
       if constexpr (R == 3) {
-        if constexpr (!INV) r8_dif<H, D == 1, ZHI>(x, w, M); else r8_dit<H, D == 1>(x, w, M);
+        if constexpr (!INV) r8_dif<H, D == 1, ZHI, KIN, KOUT>(x, w, M); else r8_dit<H, D == 1, KIN, KOUT>(x, w, M);
       } else if constexpr (R == 2) {
-        r4_unit<H, D == 1, INV>(x, w, M);
+        r4_unit<H, D == 1, INV, KIN, KOUT>(x, w, M);
       } else {
-        r2_unit<H, D == 1, INV>(x, w, M);
+        r2_unit<H, D == 1, INV, KIN, KOUT>(x, w, M);
       }
 #pragma unroll
       for (int q = 0; q < NP; ++q) s[v][a0 + L::padj(q * D)] = x[q];
@@ -266,28 +267,33 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
 }
 
 // Forward (DIF) rounds: largest distance first.  REM = log2 of the sub-transform still to do.
-template <class L, int REM, int H, int NV, bool ZTOP = false>
+// KIN bounds the values found in the tile before the first round, KOUT the values left by the
+// last one; between rounds the forward contract KF holds.  ZTOP: upper half of the input is zero.
+template <class L, int REM, int H, int NV, bool ZTOP, int KIN, int KOUT>
 __device__ __forceinline__ void dif_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
-  if constexpr (REM >= 3) {
-    ntt_round<L, 3, REM - 3, false, H, NV, ZTOP>(s, tw, M);   // ZTOP: upper half of the transform input is zero
-    if constexpr (REM > 3) { __syncthreads(); dif_rounds<L, REM - 3, H, NV>(s, tw, M); }
-  } else if constexpr (REM == 2) {
-    ntt_round<L, 2, 0, false, H, NV>(s, tw, M);
-  } else if constexpr (REM == 1) {
-    ntt_round<L, 1, 0, false, H, NV>(s, tw, M);
+  constexpr int KF = Arith<H>::KF;
+  constexpr int kin = (REM == L::LOGT) ? KIN : KF;
+  constexpr bool zt = ZTOP && REM == L::LOGT;
+  if constexpr (REM > 3) {
+    ntt_round<L, 3, REM - 3, false, H, NV, zt, kin, KF>(s, tw, M);
+    __syncthreads();
+    dif_rounds<L, REM - 3, H, NV, ZTOP, KIN, KOUT>(s, tw, M);
+  } else {
+    ntt_round<L, REM, 0, false, H, NV, zt, kin, KOUT>(s, tw, M);
   }
 }
 
 // Inverse (DIT) rounds: the same partition walked from the smallest distance up.
-template <class L, int REM, int H, int NV>
+template <class L, int REM, int H, int NV, int KIN, int KOUT>
 __device__ __forceinline__ void dit_rounds(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
-  if constexpr (REM >= 3) {
-    if constexpr (REM > 3) { dit_rounds<L, REM - 3, H, NV>(s, tw, M); __syncthreads(); }
-    ntt_round<L, 3, REM - 3, true, H, NV>(s, tw, M);
-  } else if constexpr (REM == 2) {
-    ntt_round<L, 2, 0, true, H, NV>(s, tw, M);
-  } else if constexpr (REM == 1) {
-    ntt_round<L, 1, 0, true, H, NV>(s, tw, M);
+  constexpr int KI = Arith<H>::KI;
+  constexpr int kout = (REM == L::LOGT) ? KOUT : KI;
+  if constexpr (REM > 3) {
+    dit_rounds<L, REM - 3, H, NV, KIN, KOUT>(s, tw, M);
+    __syncthreads();
+    ntt_round<L, 3, REM - 3, true, H, NV, false, KI, kout>(s, tw, M);
+  } else {
+    ntt_round<L, REM, 0, true, H, NV, false, KIN, kout>(s, tw, M);
   }
 }
 
@@ -330,7 +336,7 @@ __device__ __forceinline__ void row_load(uint32_t *s, const uint32_t *in, long l
 template <class L, int H>
 __device__ __forceinline__ void row_store(const uint32_t *s, uint32_t *out, long long row0, long long nrows,
                                           const Arith<H> &M, bool canon) {
-  // stored values obey the forward or the inverse contract; KI >= KF covers both
+  // stored values are below KI*p (the last round of either direction is asked for that)
   constexpr int T = L::T;
   if constexpr (T >= 4) {
     constexpr int NV4 = L::NT * T / 4;
@@ -338,14 +344,14 @@ __device__ __forceinline__ void row_store(const uint32_t *s, uint32_t *out, long
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       if (row0 + c < nrows) {
         uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c, j));
-        if (canon) { x.x = M.canon(M.inI(x.x)); x.y = M.canon(M.inI(x.y)); x.z = M.canon(M.inI(x.z)); x.w = M.canon(M.inI(x.w)); }
+        if (canon) { x.x = M.canon(V<Arith<H>::KI>{x.x}); x.y = M.canon(V<Arith<H>::KI>{x.y}); x.z = M.canon(V<Arith<H>::KI>{x.z}); x.w = M.canon(V<Arith<H>::KI>{x.w}); }
         *reinterpret_cast<uint4 *>(out + (row0 + c) * T + j) = x;
       }
     }
   } else {
     for (int v = threadIdx.x; v < L::NT * T; v += WG) {
       const int c = v / T, j = v % T;
-      if (row0 + c < nrows) { uint32_t x = s[L::addr(c, j)]; out[(row0 + c) * T + j] = canon ? M.canon(M.inI(x)) : x; }
+      if (row0 + c < nrows) { uint32_t x = s[L::addr(c, j)]; out[(row0 + c) * T + j] = canon ? M.canon(V<Arith<H>::KI>{x}) : x; }
     }
   }
 }
@@ -369,27 +375,28 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
     row_load<L>(sa, A.in0, row0, A.nrows);
     if (MODE == ROW_MUL) row_load<L>(sb, A.in1, row0, A.nrows);
     __syncthreads();
-    if (MODE == ROW_FWD) {
+    constexpr int KFc = Arith<H>::KF, KIc = Arith<H>::KI, KPc = Arith<H>::KP;
+    if (MODE == ROW_FWD) {         // inputs canonical or fresh from a constant multiply (< 2p)
       uint32_t *const v[1] = {sa};
-      dif_rounds<L, LOGT, H, 1>(v, twf, M);
-    } else if (MODE == ROW_INV) {
+      dif_rounds<L, LOGT, H, 1, false, KFc, KIc>(v, twf, M);
+    } else if (MODE == ROW_INV) {  // inputs of unknown history: the widest inverse bound
       uint32_t *const v[1] = {sa};
-      dit_rounds<L, LOGT, H, 1>(v, twi, M);
+      dit_rounds<L, LOGT, H, 1, KIc, KIc>(v, twi, M);
     } else {
       uint32_t *const v2[2] = {sa, sb};
-      dif_rounds<L, LOGT, H, 2>(v2, twf, M);
+      dif_rounds<L, LOGT, H, 2, false, KFc, KPc>(v2, twf, M);
       __syncthreads();
       // pointwise product (plus the optional n^{-1} R^2 factor), into sa
       for (int i = threadIdx.x; i < L::NT * T; i += WG) {
         const int c = i >> LOGT, j = i & (T - 1);
         const int ad = L::addr(c, j);
-        V<2> pr = M.mul2(M.inF(sa[ad]), M.inF(sb[ad]));
+        V<2> pr = M.mul2(V<KPc>{sa[ad]}, V<KPc>{sb[ad]});
         if (A.scale) pr = M.mul(pr, A.scale);
         sa[ad] = pr.v;
       }
       __syncthreads();
       uint32_t *const v[1] = {sa};
-      dit_rounds<L, LOGT, H, 1>(v, twi, M);
+      dit_rounds<L, LOGT, H, 1, 2, KIc>(v, twi, M);
     }
     __syncthreads();
     row_store<L, H>(sa, A.out, row0, A.nrows, M, A.canon_out != 0);
@@ -411,13 +418,16 @@ constexpr int ROW9_PAD = 576;  // 512 + 8 pad words per 64
 #ifndef NTTX_ROW9_WAVES
 #define NTTX_ROW9_WAVES 4
 #endif
-template <int H>
+// CANON: outputs fully reduced (single-pass products); otherwise they are left unreduced for the
+// inverse column pass, which multiplies them by its four-step constants first.
+template <int H, bool CANON>
 __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[(WG / 64) * 2 * ROW9_PAD];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses stay in SGPRs
   uint32_t *sa = lds + wave * 2 * ROW9_PAD, *sb = sa + ROW9_PAD;
   const Arith<H> M(A.ctx);
+  constexpr int KF = Arith<H>::KF, KI = Arith<H>::KI, KP = Arith<H>::KP, KANY = Arith<H>::KANY;
   const int k8 = lane >> 3, m8 = lane & 7;
   const int o1 = lane;                       // R1: + 72 q
   const int o2 = 72 * k8 + m8;               // R2: + 8 j
@@ -442,8 +452,8 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
   }
   for (; row < A.nrows; row += nwaves) {
     // forward round 1 (distances 256, 128, 64)
-    r8_dif<H, false>(na, wf1, M);
-    r8_dif<H, false>(nb, wf1, M);
+    r8_dif<H, false, false, 2, KF>(na, wf1, M);
+    r8_dif<H, false, false, 2, KF>(nb, wf1, M);
 #pragma unroll
     for (int q = 0; q < 8; ++q) { sa[o1 + 72 * q] = na[q]; sb[o1 + 72 * q] = nb[q]; }
     const long long nrow = row + nwaves;
@@ -457,8 +467,8 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a[j] = sa[o2 + 8 * j]; b[j] = sb[o2 + 8 * j]; }
     // forward round 2 (32, 16, 8)
-    r8_dif<H, false>(a, wf2, M);
-    r8_dif<H, false>(b, wf2, M);
+    r8_dif<H, false, false, KF, KF>(a, wf2, M);
+    r8_dif<H, false, false, KF, KF>(b, wf2, M);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sa[o2 + 8 * j] = a[j]; sb[o2 + 8 * j] = b[j]; }
     __builtin_amdgcn_wave_barrier();
@@ -469,38 +479,33 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
       b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
     }
     // forward round 3 (4, 2, 1), pointwise product, inverse round 1 (1, 2, 4): all on a lane's own 8 points
-    r8_dif<H, true>(a, wf3, M);
-    r8_dif<H, true>(b, wf3, M);
+    r8_dif<H, true, false, KF, KP>(a, wf3, M);
+    r8_dif<H, true, false, KF, KP>(b, wf3, M);
     if (A.scale) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = M.mul(M.mul2(M.inF(a[j]), M.inF(b[j])), A.scale).v;
+      for (int j = 0; j < 8; ++j) a[j] = M.mul(M.mul2(V<KP>{a[j]}, V<KP>{b[j]}), A.scale).v;
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = M.mul2(M.inF(a[j]), M.inF(b[j])).v;
+      for (int j = 0; j < 8; ++j) a[j] = M.mul2(V<KP>{a[j]}, V<KP>{b[j]}).v;
     }
-    r8_dit<H, true>(a, wi3, M);
+    r8_dit<H, true, 2, KI>(a, wi3, M);
     *reinterpret_cast<uint4 *>(sa + o3) = make_uint4(a[0], a[1], a[2], a[3]);
     *reinterpret_cast<uint4 *>(sa + o3 + 4) = make_uint4(a[4], a[5], a[6], a[7]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = sa[o2 + 8 * j];
     // inverse round 2 (8, 16, 32)
-    r8_dit<H, false>(a, wi2, M);
+    r8_dit<H, false, KI, KI>(a, wi2, M);
 #pragma unroll
     for (int j = 0; j < 8; ++j) sa[o2 + 8 * j] = a[j];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = sa[o1 + 72 * q];
     // inverse round 3 (64, 128, 256)
-    r8_dit<H, false>(a, wi1, M);
+    r8_dit<H, false, KI, (CANON ? 1 : KANY)>(a, wi1, M);
     uint32_t *po = A.out + row * 512;
-    if (A.canon_out) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) po[lane + 64 * q] = M.canon(M.inI(a[q]));
-    } else {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) po[lane + 64 * q] = a[q];
-    }
+    for (int q = 0; q < 8; ++q) po[lane + 64 * q] = a[q];
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -529,7 +534,7 @@ struct ColArgs {
 // ZHI (forward only): each block is a zero-padded vector whose first nvalid <= N/2 words hold data.
 // Rows from T/2 on are never read (half the input traffic) and the first butterfly stage degenerates.
 template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false>
-__global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
+__global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColArgs A) {
   using L = ColLayout<LOGT, LOGC, NTHR>;
   constexpr int T = L::T, COLS = L::COLS;
   constexpr int LPR = COLS / 4, LOG_LPR = LOGC - 2;
@@ -572,14 +577,24 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
       return x;
     }
   };
+  // 64-byte tiles: the two halves of a 128-byte line go to workgroups 8 block slots apart, which the
+  // dispatcher places on the same XCD, so that XCD's L2 merges their half-line writes and serves the
+  // second half-line read (a placement heuristic for speed; any placement is correct).
+  auto remap = [&](long long t0) -> long long {
+    if constexpr (LOGC == 4) {
+      if ((t0 | 15) < ntiles) { const long long r = t0 & 15; return (t0 & ~15ll) + ((r & 7) << 1) + (r >> 3); }
+    }
+    return t0;
+  };
   uint4 nx[PERL];
-  long long t = blockIdx.x;
-  if (t < ntiles) {
-    const long long base = tile_base(t);
+  long long t0 = blockIdx.x;
+  if (t0 < ntiles) {
+    const long long t = remap(t0), base = tile_base(t);
 #pragma unroll
     for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, t, j0 + k * RSTEP);
   }
-  for (; t < ntiles; t += gridDim.x) {
+  for (; t0 < ntiles; t0 += gridDim.x) {
+    const long long t = remap(t0);
     const long long gbase = tile_base(t), fbase = fs_base(t);
     __syncthreads();   // previous tile's LDS reads are done
 #pragma unroll
@@ -588,21 +603,23 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
       const int j = j0 + k * RSTEP;
       if (INV) {
         const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
-        x.x = M.mul(M.inI(x.x), f.x).v; x.y = M.mul(M.inI(x.y), f.y).v;
-        x.z = M.mul(M.inI(x.z), f.z).v; x.w = M.mul(M.inI(x.w), f.w).v;
+        x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
+        x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
       }
       *reinterpret_cast<uint4 *>(s + L::addr(c4, j)) = x;
     }
-    const long long tn = t + gridDim.x;
-    if (tn < ntiles) {
-      const long long base = tile_base(tn);
+    if (t0 + gridDim.x < ntiles) {
+      const long long tn = remap(t0 + gridDim.x), base = tile_base(tn);
 #pragma unroll
       for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, tn, j0 + k * RSTEP);
     }
     __syncthreads();
     uint32_t *const vec[1] = {s};
-    if constexpr (!INV) dif_rounds<L, LOGT, H, 1, ZHI>(vec, tw, M);
-    else dit_rounds<L, LOGT, H, 1>(vec, tw, M);
+    // forward: inputs are canonical or fresh from a constant multiply (< 2p); outputs go straight into
+    // the four-step multiply, so the last round leaves them unreduced.  inverse: inputs were just
+    // multiplied (< 2p); outputs are kept below KI*p for the canonical store.
+    if constexpr (!INV) dif_rounds<L, LOGT, H, 1, ZHI, 2, Arith<H>::KANY>(vec, tw, M);
+    else dit_rounds<L, LOGT, H, 1, 2, Arith<H>::KI>(vec, tw, M);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -610,10 +627,13 @@ __global__ void __launch_bounds__(NTHR) col_kernel(ColArgs A) {
       uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c4, j));
       if (!INV) {
         const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
-        x.x = M.mul(M.inI(x.x), f.x).v; x.y = M.mul(M.inI(x.y), f.y).v;
-        x.z = M.mul(M.inI(x.z), f.z).v; x.w = M.mul(M.inI(x.w), f.w).v;
+        x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
+        x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
       }
-      if (A.canon_out) { x.x = M.canon(M.inI(x.x)); x.y = M.canon(M.inI(x.y)); x.z = M.canon(M.inI(x.z)); x.w = M.canon(M.inI(x.w)); }
+      if (A.canon_out) {   // forward results are < 2p after the multiply, inverse results < KI*p
+        x.x = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.x}); x.y = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.y});
+        x.z = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.z}); x.w = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.w});
+      }
       *reinterpret_cast<uint4 *>(out + gbase + ((long long)j << logS) + c4) = x;
     }
   }

@@ -9,14 +9,19 @@
 
 // vector = 2^18 words (1 MiB) viewed as 512 rows x 512 words; batch of such vectors.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int LOGC, int NTHR, int MODE, int NT = 0>   // MODE 0: read+write, 1: read only, 2: write only; NT: 1 = nontemporal loads, 2 = stores, 3 = both
+template <int LOGC, int NTHR, int MODE, int NT = 0, int PAIR = 0>   // MODE 0: read+write, 1: read only, 2: write only; NT: 1 = nontemporal loads, 2 = stores, 3 = both
 __global__ void __launch_bounds__(NTHR) tile_copy(const uint32_t *in, uint32_t *out, long long ntiles) {
   constexpr int COLS = 1 << LOGC, LPR = COLS / 4, LOG_LPR = LOGC - 2;
   constexpr int PER = 512 * LPR / NTHR, RSTEP = NTHR / LPR;
   const int log_tpb = 9 - LOGC;
   const int j0 = threadIdx.x >> LOG_LPR, c4 = (threadIdx.x & (LPR - 1)) * 4;
   uint32_t acc = 0;
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (long long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+    long long t = t0;
+    if (PAIR) {   // blocks b and b+8 (same XCD under round-robin dispatch) take the two halves of a 128-byte line
+      const long long g = t0 >> 4, r = t0 & 15;          // groups of 16 consecutive block slots
+      t = (g << 4) + ((r & 7) << 1) + (r >> 3);
+    }
     const long long blk = t >> log_tpb, ct = t & ((1 << log_tpb) - 1);
     const long long base = (blk << 18) + (ct << LOGC) + c4;
     uint4 x[PER];
@@ -70,7 +75,7 @@ int main() {
   CHECK(hipMemset(a, 1, words * 4)); CHECK(hipMemset(b, 2, words * 4));
   const double gb = words * 4 / 1e9;
   const char *mn[3] = {"read+write", "read only", "write only"};
-  for (int grid : {512, 2048}) {
+  for (int grid : {1024, 2048, 4096}) {
     printf("grid %d\n", grid);
 #define FLAT(M) { double ms = timeit([&] { flat_copy<M><<<grid, 256>>>((const uint4 *)a, (uint4 *)b, words / 4); }); \
       printf("  flat 16B/lane      %-10s %7.3f ms  %7.1f GB/s\n", mn[M], ms, gb * (M == 0 ? 2 : 1) / ms * 1e3); }
@@ -85,6 +90,10 @@ int main() {
 #define TILENT(LC, NT_, M, NTF) { long long nt = (long long)batch << (9 - LC); \
       double ms = timeit([&] { tile_copy<LC, NT_, M, NTF><<<grid, NT_>>>(a, b, nt); }); \
       printf("  tile seg %3d B thr %3d %-10s nt=%d %7.3f ms  %7.1f GB/s\n", 4 << LC, NT_, mn[M], NTF, ms, gb * (M == 0 ? 2 : 1) / ms * 1e3); }
+#define TILEP(LC, NT_, M) { long long nt = (long long)batch << (9 - LC); \
+      double ms = timeit([&] { tile_copy<LC, NT_, M, 0, 1><<<grid, NT_>>>(a, b, nt); }); \
+      printf("  tile seg %3d B thr %3d %-10s XCD-paired %7.3f ms  %7.1f GB/s\n", 4 << LC, NT_, mn[M], ms, gb * (M == 0 ? 2 : 1) / ms * 1e3); }
+    TILEP(4, 256, 0) TILEP(4, 256, 1) TILEP(4, 256, 2)
     TILENT(5, 512, 0, 1) TILENT(5, 512, 0, 2) TILENT(5, 512, 0, 3) TILENT(5, 512, 1, 1) TILENT(5, 512, 2, 2)
   }
   return 0;
