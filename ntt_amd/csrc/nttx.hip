@@ -311,6 +311,9 @@ static int launch_col(Context *cx, bool inv, int h, int logT, const ColArgs &A0,
   return rc;
 }
 
+static dim3 ew_grid2(long long per_vec, int batch, int z = 1) {
+  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
+}
 static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 * 16); }
 
 // ---- device-resident building blocks ---------------------------------------------------
@@ -427,6 +430,7 @@ static int fill_crt_args(CrtArgs &A, uint64_t p) {
   if (p < 2 || p >= (1ull << 63)) return fail(NTTX_EINVAL, "modulus out of range");
   if ((p & 1) == 0) return fail(NTTX_EINVAL, "even modulus %llu is not supported by the CRT recombination", (unsigned long long)p);
   A.pctx = make_ctx64(p);
+  A.small_p = p <= (1ull << 31) ? 1 : 0;
   const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % p);
   for (int k = 0; k < 4; ++k) A.mR[k] = h_mulmod64(kCrtPrimes[k] % p, R, p);
   return 0;
@@ -460,11 +464,16 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
   if (int rc = cx->pc.ensure(4 * vec)) return rc;
   Plan *pl[4];
   for (int k = 0; k < 4; ++k) if (int rc = get_plan(cx, kCrtPrimes[k], logL, false, &pl[k])) return rc;
-  for (int which = 0; which < 2; ++which) {
-    SplitArgs S{}; S.src = which ? d_b : d_a; S.nmod = 4; S.n = n; S.len = (int)len; S.total = (long long)batch * len;
-    for (int k = 0; k < 4; ++k) { S.dst[k] = (which ? cx->pb : cx->pa).as<uint32_t>() + (size_t)k * batch * len; S.mod[k] = kCrtPrimes[k]; }
+  {
+    SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = 4; S.n = n; S.len = (int)len;
+    S.zfill = pl[0]->npass == 1 ? (int)len : n;   // multi-pass products never read the padding
+    for (int k = 0; k < 4; ++k) {
+      S.dst[0][k] = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
+      S.dst[1][k] = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
+      S.ctx[k] = pl[k]->ctx;
+    }
     cx->prof.begin(PK_SPLIT, st);
-    hipLaunchKernelGGL(split_kernel, dim3(ew_grid(S.total)), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
     cx->prof.end(st);
     HIPCHK(hipGetLastError());
   }
@@ -477,9 +486,9 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
     if (int rc = dev_cyclic_multiply(cx, pl[k], a, b, c, batch, st, n)) return rc;
     A.res[k] = c;
   }
-  A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len; A.total = (long long)batch * A.nout;
+  A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len;
   cx->prof.begin(PK_CRT, st);
-  hipLaunchKernelGGL(crt_kernel, dim3(ew_grid(A.total)), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(crt_kernel, ew_grid2(A.nout, batch), dim3(256), 0, st, A);
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
   return 0;
@@ -670,8 +679,8 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
     HIPCHK(hipMemcpy(d, res[k], bytes, hipMemcpyHostToDevice));
     A.res[k] = d;
   }
-  A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len; A.total = nout;
-  hipLaunchKernelGGL(crt_kernel, dim3(ew_grid(A.total)), dim3(256), 0, 0, A);
+  A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len;
+  hipLaunchKernelGGL(crt_kernel, ew_grid2(nout, 1), dim3(256), 0, 0, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
   return 0;
@@ -693,13 +702,16 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   if (int rc = cx->outb.ensure((size_t)batch * nout * 4)) return rc;
   HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
-  const long long total = (long long)batch * len;
-  hipLaunchKernelGGL(pad_kernel, dim3(ew_grid(total)), dim3(256), 0, 0, cx->in_a.as<uint32_t>(), cx->pa.as<uint32_t>(), p, n, (int)len, total);
-  hipLaunchKernelGGL(pad_kernel, dim3(ew_grid(total)), dim3(256), 0, 0, cx->in_b.as<uint32_t>(), cx->pb.as<uint32_t>(), p, n, (int)len, total);
-  HIPCHK(hipGetLastError());
+  {
+    PadArgs P{}; P.src[0] = cx->in_a.as<uint32_t>(); P.src[1] = cx->in_b.as<uint32_t>();
+    P.dst[0] = cx->pa.as<uint32_t>(); P.dst[1] = cx->pb.as<uint32_t>(); P.ctx = pl->ctx; P.n = n; P.len = (int)len;
+    P.zfill = pl->npass == 1 ? (int)len : n;
+    hipLaunchKernelGGL(pad_kernel, ew_grid2(P.zfill, batch, 2), dim3(256), 0, 0, P);
+    HIPCHK(hipGetLastError());
+  }
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), batch, nullptr, n)) return rc;
   const long long tout = (long long)batch * nout;
-  hipLaunchKernelGGL((unpad_kernel<uint32_t>), dim3(ew_grid(tout)), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len, tout);
+  hipLaunchKernelGGL((unpad_kernel<uint32_t>), ew_grid2(nout, batch), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)tout * 4, hipMemcpyDeviceToHost));
   return 0;
@@ -758,14 +770,15 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
   HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
-  for (int which = 0; which < 2; ++which) {
-    SplitArgs S{}; S.src = (which ? cx->in_b : cx->in_a).as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len; S.total = len;
-    S.dst[0] = (which ? cx->pb : cx->pa).as<uint32_t>(); S.mod[0] = (uint32_t)p;
-    hipLaunchKernelGGL(split_kernel, dim3(ew_grid(S.total)), dim3(256), 0, 0, S);
+  {
+    SplitArgs S{}; S.src[0] = cx->in_a.as<uint64_t>(); S.src[1] = cx->in_b.as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len;
+    S.zfill = pl->npass == 1 ? (int)len : n;
+    S.dst[0][0] = cx->pa.as<uint32_t>(); S.dst[1][0] = cx->pb.as<uint32_t>(); S.ctx[0] = pl->ctx;
+    hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, 1, 2), dim3(256), 0, 0, S);
   }
   HIPCHK(hipGetLastError());
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr, n)) return rc;
-  hipLaunchKernelGGL((unpad_kernel<uint64_t>), dim3(ew_grid(nout)), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len, (long long)nout);
+  hipLaunchKernelGGL((unpad_kernel<uint64_t>), ew_grid2(nout, 1), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
   return 0;

@@ -654,48 +654,66 @@ __global__ void bitrev_kernel(const uint32_t *in, uint32_t *out, int logn, long 
   }
 }
 
-// u64 coefficients -> zero-padded u32 residues mod up to 4 primes (residue split,
-// main.cc:292-303).  src is [batch][n]; dst[k] is [batch][len].
+// u64 coefficients -> u32 residues mod up to 4 primes (residue split, main.cc:292-303).
+// src is [batch][n]; dst[k] is [batch][len].  x = hi*2^32 + lo, so x mod m = hi*R + lo mod m with
+// R = 2^32: two Montgomery products, REDC(hi * R^2) and REDC(lo * R), instead of a 64-bit division.
+// Words n..zfill-1 of every vector are zeroed (zfill = len for single-pass lengths, whose kernels
+// read the padding; zfill = n where the column pass never reads it).
 struct SplitArgs {
-  const uint64_t *src;
-  uint32_t *dst[4];
-  uint32_t mod[4];
+  const uint64_t *src[2];   // a and b (blockIdx.z)
+  uint32_t *dst[2][4];
+  PrimeCtx ctx[4];
   int nmod;
-  int n, len;
-  long long total;  // batch * len
+  int n, len, zfill;
 };
 __global__ void split_kernel(SplitArgs A) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.total; i += (long long)gridDim.x * blockDim.x) {
-    const long long b = i / A.len;
-    const int j = (int)(i - b * A.len);
-    const uint64_t x = (j < A.n) ? A.src[b * A.n + j] : 0ull;
-    for (int k = 0; k < A.nmod; ++k) A.dst[k][i] = (uint32_t)(x % A.mod[k]);
+  const long long b = blockIdx.y;
+  const uint64_t *src = A.src[blockIdx.z] + b * A.n;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
+    const uint64_t x = (j < A.n) ? src[j] : 0ull;
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < A.nmod) {
+        const PrimeCtx c = A.ctx[k];
+        const uint32_t h = csub(mont_mul_lazy(hi, c.r2, c.p, c.npinv), c.p);   // hi * 2^32 mod m
+        const uint32_t l = csub(mont_mul_lazy(lo, c.one, c.p, c.npinv), c.p);  // lo mod m
+        A.dst[blockIdx.z][k][b * A.len + j] = csub(h + l, c.p);
+      }
+    }
   }
 }
 
-// i32 / u32 coefficients -> zero-padded canonical residues
-__global__ void pad_kernel(const uint32_t *src, uint32_t *dst, uint32_t p, int n, int len, long long total) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long b = i / len;
-    const int j = (int)(i - b * len);
-    const uint32_t x = (j < n) ? src[b * n + j] : 0u;
-    dst[i] = x >= p ? x % p : x;
+// i32 / u32 coefficients -> zero-padded canonical residues; src [batch][n] -> dst [batch][len]
+struct PadArgs {
+  const uint32_t *src[2];
+  uint32_t *dst[2];
+  PrimeCtx ctx;
+  int n, len, zfill;
+};
+__global__ void pad_kernel(PadArgs A) {
+  const long long b = blockIdx.y;
+  const uint32_t *src = A.src[blockIdx.z] + b * A.n;
+  uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
+    const uint32_t x = (j < A.n) ? src[j] : 0u;
+    // inputs are canonical in the reference's harness; anything larger is reduced like main.cc:300 does
+    dst[j] = x >= A.ctx.p ? csub(mont_mul_lazy(x, A.ctx.one, A.ctx.p, A.ctx.npinv), A.ctx.p) : x;
   }
 }
 
 // gather the first nout words of every length-len vector (u32 -> u32 or u64)
 template <class OUT>
-__global__ void unpad_kernel(const uint32_t *src, OUT *dst, int nout, int len, long long total) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long b = i / nout;
-    const int j = (int)(i - b * nout);
-    dst[i] = (OUT)src[b * len + j];
-  }
+__global__ void unpad_kernel(const uint32_t *src, OUT *dst, int nout, int len) {
+  const long long b = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
+    dst[b * nout + j] = (OUT)src[b * len + j];
 }
 
 // Multi-prime CRT recombination (replaces the 128-bit sum/% M loop of main.cc:323-337):
 // Garner mixed-radix digits v_k, then Horner evaluation of
 //   x = v0 + m0 (v1 + m1 (v2 + m2 v3))  modulo the caller's p on 64-bit Montgomery lanes.
+// The moduli are in ascending order, so a digit v_q < m_q is already reduced modulo every later m_k.
 struct CrtArgs {
   const uint32_t *res[4];   // [batch][len] canonical residues per prime
   uint64_t *out;            // [batch][nout]
@@ -704,33 +722,34 @@ struct CrtArgs {
   PrimeCtx64 pctx;          // caller modulus
   uint64_t mR[4];           // m_k * 2^64 mod p
   int nmod, nout, len;
-  long long total;          // batch * nout
+  int small_p;              // p <= 2^31: digits must be reduced modulo p before they are added
 };
 __global__ void crt_kernel(CrtArgs A) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.total; i += (long long)gridDim.x * blockDim.x) {
-    const long long b = i / A.nout;
-    const int j = (int)(i - b * A.nout);
+  const long long b = blockIdx.y;
+  const uint64_t p = A.pctx.p;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.nout; j += gridDim.x * blockDim.x) {
     const long long src = b * A.len + j;
     uint32_t v[4];
-    for (int k = 0; k < A.nmod; ++k) {
-      const uint32_t mk = A.ctx[k].p;
-      uint32_t t = A.res[k][src];
-      for (int q = 0; q < k; ++q) {
-        uint32_t vq = v[q] % mk;
-        t = t >= vq ? t - vq : t + mk - vq;
-        t = mont_mul(t, A.inv[q][k], mk, A.ctx[k].npinv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < A.nmod) {
+        const uint32_t mk = A.ctx[k].p;
+        uint32_t t = A.res[k][src];
+#pragma unroll
+        for (int q = 0; q < k; ++q) {
+          const uint32_t d = t - v[q];
+          t = mont_mul(t >= v[q] ? d : d + mk, A.inv[q][k], mk, A.ctx[k].npinv);
+        }
+        v[k] = t;
       }
-      v[k] = t;
     }
-    const uint64_t p = A.pctx.p;
-    uint64_t r = v[A.nmod - 1] % p;
+    uint64_t r = A.small_p ? v[A.nmod - 1] % p : v[A.nmod - 1];
     for (int k = A.nmod - 2; k >= 0; --k) {
       r = mont_mul64(r, A.mR[k], p, A.pctx.npinv);
-      const uint64_t add = v[k] % p;
-      r += add;
+      r += A.small_p ? v[k] % p : v[k];
       if (r >= p) r -= p;
     }
-    A.out[i] = r;
+    A.out[b * A.nout + j] = r;
   }
 }
 
