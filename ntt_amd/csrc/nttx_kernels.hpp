@@ -54,9 +54,19 @@ struct Arith {
   // a value about to be multiplied by a Montgomery constant needs no reduction at all
   static constexpr int KANY = H;
   uint32_t p, npinv;
-  __device__ __forceinline__ Arith(const PrimeCtx &c) : p(c.p), npinv(c.npinv) {}
+  // The multiples of p also live in vector registers: on gfx950 a 32-bit add/subtract whose
+  // operands are all VGPRs issues in about 2.5 cycles per wave, one with a scalar or literal
+  // operand in about 4.2.  Copies that no butterfly uses are dropped by the compiler.
+  uint32_t vp[H + 1];
+  __device__ __forceinline__ Arith(const PrimeCtx &c) : p(c.p), npinv(c.npinv) {
+#pragma unroll
+    for (int k = 1; k <= H; ++k) asm("v_mov_b32 %0, %1" : "=v"(vp[k]) : "s"((uint32_t)k * c.p));
+  }
   template <int C>
-  __device__ __forceinline__ uint32_t kp() const { return (uint32_t)C * p; }   // scalar, hoisted
+  __device__ __forceinline__ uint32_t kp() const {
+    static_assert(C >= 1 && C <= H, "multiple of p outside the modulus class");
+    return vp[C];
+  }
   // one conditional subtraction: [0, K p) -> [0, ceil(K/2) p)
   template <int K>
   __device__ __forceinline__ V<(K + 1) / 2> half(V<K> x) const {
