@@ -97,6 +97,39 @@ int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int 
  * the final permutation (forward output stays in bit-reversed order). */
 int nttx_dev_ntt_u32(void *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch, void *stream);
 
+/* ---- building blocks for work split over several processes (one per GPU) --------------- */
+
+/* The k-th modulus of the CRT path, k = 0..3 (the constants of main.cc:245-248). */
+int nttx_crt_prime(int k, uint32_t *prime);
+
+/* The per-prime part of the CRT path (residue split main.cc:292-303 and ntt_compute_omp
+ * main.cc:306-311) for the primes selected by prime_mask (bit k = modulus k): d_res receives, for
+ * each selected prime in ascending k, the [batch][len] canonical u32 residues of the products
+ * (len = smallest power of two >= 2n).  d_a, d_b are [batch][n] u64 in device memory.  A process
+ * that owns some of the primes calls this, exchanges residue slices with its peers and recombines
+ * with nttx_dev_crt_recombine_u64 (the reference gives each prime a thread, main_pthread.cc:413-428). */
+int nttx_dev_crt_residues_u64(const void *d_a, const void *d_b, void *d_res, int n, int prime_mask, int batch,
+                              void *stream);
+
+/* CRT recombination of a slice (main.cc:323-337, crt_thread_func main_pthread.cc:293-310 works on
+ * [start,end) the same way): d_out[i] = x_i mod p for i < count, where x_i < M has the residues
+ * d_rk[i] modulo modulus k.  All device memory, u32 in, u64 out. */
+int nttx_dev_crt_recombine_u64(const void *d_r0, const void *d_r1, const void *d_r2, const void *d_r3, void *d_out,
+                               long long count, uint64_t p, void *stream);
+
+/* One column pass of a length-2^log_len transform whose vector, seen as a 2^log_t x S matrix
+ * (S = 2^(log_len-log_t), element (j, s) = v[j*S + s]), is split by columns over processes: d_x is
+ * this process's dense [2^log_t][cols] slab of columns col0 .. col0+cols-1, transformed in place.
+ * forward: length-2^log_t transform down every column (rows come out in bit-reversed order), then
+ * element (j', s) times w^((col0+s) * bitrev(j')), w the primitive 2^log_len-th root
+ * 3^((p-1)/2^log_len) of main.cc:156; inverse: the inverse factors and 2^-log_t first, then the
+ * inverse transform taking rows in bit-reversed order.  zero_hi != 0 (forward): rows from
+ * 2^(log_t-1) on are known to be zero and are not read.  Outputs canonical.  Together with a
+ * transpose between the processes and length-S products of the rows this is one product of
+ * length 2^log_len (no counterpart in the reference, whose arrays stop at 300000, main.cc:228). */
+int nttx_dev_colpass_u32(void *d_x, int log_len, int log_t, long long col0, int cols, uint32_t p, int inverse,
+                         int zero_hi, void *stream);
+
 /* Pre-size the internal workspace so that later device-resident calls allocate nothing. */
 int nttx_reserve(int len, int batch, int nprimes);
 

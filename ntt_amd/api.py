@@ -35,6 +35,10 @@ _SIGS = [
     ("nttx_dev_poly_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_crt_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_dev_ntt_u32", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("nttx_crt_prime", C.c_int, [C.c_int, _u32p]),
+    ("nttx_dev_crt_residues_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("nttx_dev_crt_recombine_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint64, C.c_void_p]),
+    ("nttx_dev_colpass_u32", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_reserve", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("nttx_profile_enable", C.c_int, [C.c_int]),
     ("nttx_profile_reset", C.c_int, []),
@@ -188,6 +192,28 @@ def dev_crt_multiply_u64(d_a: int, d_b: int, d_ab: int, n: int, p: int, batch: i
 
 def dev_ntt_u32(d_x: int, length: int, p: int, invert: bool, bit_reversed_out: bool, batch: int, stream: int = 0):
     _check(lib().nttx_dev_ntt_u32(d_x, length, p, int(bool(invert)), int(bool(bit_reversed_out)), batch, stream))
+
+
+def crt_prime(k: int) -> int:
+    v = C.c_uint32(0)
+    _check(lib().nttx_crt_prime(k, C.byref(v)))
+    return v.value
+
+
+def dev_crt_residues_u64(d_a: int, d_b: int, d_res: int, n: int, prime_mask: int, batch: int, stream: int = 0):
+    """Residues of the products modulo the CRT primes in prime_mask -> [primes][batch][len] u32."""
+    _check(lib().nttx_dev_crt_residues_u64(d_a, d_b, d_res, n, prime_mask, batch, stream))
+
+
+def dev_crt_recombine_u64(d_r, d_out: int, count: int, p: int, stream: int = 0):
+    """CRT recombination of a slice: d_r = four device pointers to `count` u32 residues each."""
+    _check(lib().nttx_dev_crt_recombine_u64(d_r[0], d_r[1], d_r[2], d_r[3], d_out, count, p, stream))
+
+
+def dev_colpass_u32(d_x: int, log_len: int, log_t: int, col0: int, cols: int, p: int, invert: bool, zero_hi: bool = False,
+                    stream: int = 0):
+    """One column pass over this process's [2^log_t][cols] slab of a length-2^log_len transform."""
+    _check(lib().nttx_dev_colpass_u32(d_x, log_len, log_t, col0, cols, p, int(bool(invert)), int(bool(zero_hi)), stream))
 
 
 KERNEL_KINDS = ("col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv", "split", "crt", "misc")

@@ -72,6 +72,15 @@ struct Plan {
   }
 };
 
+// Tables of one column pass over a slab of columns (a transform shared by several processes):
+// the stage table of the length-T column transforms and the four-step factors of the slab.
+struct Slab {
+  uint32_t *tw = nullptr, *fs = nullptr;
+  PrimeCtx ctx{};
+  int hclass = 2;
+  ~Slab() { if (tw) (void)hipFree(tw); if (fs) (void)hipFree(fs); }
+};
+
 constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 
 static int decompose(int k, int lt[3]) {
@@ -120,6 +129,7 @@ struct Context {
   Profiler prof;
   std::mutex mu;
   std::map<std::tuple<uint32_t, int, bool>, std::unique_ptr<Plan>> plans;
+  std::map<std::tuple<uint32_t, int, int, long long, int, bool>, std::unique_ptr<struct Slab>> slabs;
   // workspace
   DevBuf wa, wb;            // transformed copies of a and b (multi-pass direct path) [batch][len]
   DevBuf in_a, in_b;        // raw host inputs staged on device
@@ -174,13 +184,15 @@ static inline uint32_t bitrev(uint32_t x, int bits) {
 }
 
 // four-step table for blocks of N = T*S words: tab[j*S + s] = wN^(s * bitrev_T(j)) * extra, Montgomery form
-static std::vector<uint32_t> fourstep_table(uint32_t wN, int logT, int logS, uint32_t extra, const PrimeCtx &c) {
+// col0 > 0: the table of columns col0 .. col0 + S - 1 of a wider matrix (s counts from col0)
+static std::vector<uint32_t> fourstep_table(uint32_t wN, int logT, int logS, uint32_t extra, const PrimeCtx &c,
+                                            uint64_t col0 = 0) {
   const size_t T = (size_t)1 << logT, S = (size_t)1 << logS;
   std::vector<uint32_t> tab(T * S);
-  const uint32_t e0 = to_mont(extra, c);
   for (size_t j = 0; j < T; ++j) {
-    const uint32_t step = to_mont(h_powmod(wN, bitrev((uint32_t)j, logT), c.p), c);
-    uint32_t cur = e0;  // Montgomery form of extra * step^s
+    const uint32_t wj = h_powmod(wN, bitrev((uint32_t)j, logT), c.p);
+    const uint32_t step = to_mont(wj, c);
+    uint32_t cur = to_mont(h_mulmod(extra, h_powmod(wj, col0, c.p), c.p), c);  // Montgomery form of extra * wj^(col0+s)
     uint32_t *row = &tab[j * S];
     for (size_t s = 0; s < S; ++s) { row[s] = cur; cur = mont_mul(cur, step, c.p, c.npinv); }
   }
@@ -494,6 +506,95 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
   return 0;
 }
 
+// residues of the products modulo the CRT primes selected by prime_mask (bit k = kCrtPrimes[k]):
+// d_res gets [selected primes, ascending k][batch][len] canonical u32 (the per-prime half of
+// main.cc:292-311, for processes that each own some of the primes)
+static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_b, uint32_t *d_res, int n, int prime_mask,
+                            int batch, hipStream_t st) {
+  const int logL = log2_ceil_len(n);
+  if (logL > 21) return fail(NTTX_ERANGE, "length 2^%d exceeds the CRT prime set (2^21)", logL);
+  if (prime_mask <= 0 || prime_mask > 15) return fail(NTTX_EINVAL, "prime mask must select 1..4 of the CRT primes");
+  const long long len = 1ll << logL;
+  const size_t vec = (size_t)batch * len * 4;
+  int sel[4], ns = 0;
+  for (int k = 0; k < 4; ++k) if (prime_mask >> k & 1) sel[ns++] = k;
+  if (int rc = cx->pa.ensure(ns * vec)) return rc;
+  if (int rc = cx->pb.ensure(ns * vec)) return rc;
+  Plan *pl[4];
+  for (int i = 0; i < ns; ++i) if (int rc = get_plan(cx, kCrtPrimes[sel[i]], logL, false, &pl[i])) return rc;
+  SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
+  S.zfill = pl[0]->npass == 1 ? (int)len : n;
+  for (int i = 0; i < ns; ++i) {
+    S.dst[0][i] = cx->pa.as<uint32_t>() + (size_t)i * batch * len;
+    S.dst[1][i] = cx->pb.as<uint32_t>() + (size_t)i * batch * len;
+    S.ctx[i] = pl[i]->ctx;
+  }
+  cx->prof.begin(PK_SPLIT, st);
+  hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
+  cx->prof.end(st);
+  HIPCHK(hipGetLastError());
+  for (int i = 0; i < ns; ++i)
+    if (int rc = dev_cyclic_multiply(cx, pl[i], S.dst[0][i], S.dst[1][i], d_res + (size_t)i * batch * len, batch, st, n)) return rc;
+  return 0;
+}
+
+// out[i] = (the integer below M with residues r_k[i]) mod p, i < count (main.cc:323-337 on a slice)
+static int dev_crt_recombine(Context *cx, const uint32_t *const r[4], uint64_t *d_out, long long count, uint64_t p, hipStream_t st) {
+  if (count < 1 || count > (1ll << 30)) return fail(NTTX_EINVAL, "count out of range");
+  CrtArgs A{};
+  if (int rc = fill_crt_args(A, p)) return rc;
+  for (int k = 0; k < 4; ++k) A.res[k] = r[k];
+  A.out = d_out; A.nout = (int)count; A.len = (int)count;
+  cx->prof.begin(PK_CRT, st);
+  hipLaunchKernelGGL(crt_kernel, ew_grid2(count, 1), dim3(256), 0, st, A);
+  cx->prof.end(st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- one column pass over a slab of columns (transform shared by several processes) -----
+// The length-L vector is the T x S matrix x[j][s] = v[j*S + s]; this process holds columns
+// col0 .. col0+cols-1 as a dense [T][cols] matrix.
+//   forward:  every column goes through the length-T decimation-in-frequency transform (rows come
+//             out in bit-reversed order) and row j' is multiplied by w_L^((col0+s) * bitrev_T(j'))
+//   inverse:  the inverse factors (times T^{-1}) first, then the decimation-in-time transform
+// A full transform is: forward slabs, transpose between processes, length-S transforms of the rows.
+static int get_slab(Context *cx, uint32_t p, int logL, int logT, long long col0, int logC, bool inverse, Slab **out) {
+  auto key = std::make_tuple(p, logL, logT, col0, logC, inverse);
+  auto it = cx->slabs.find(key);
+  if (it != cx->slabs.end()) { *out = it->second.get(); return 0; }
+  if (!direct_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %u does not support a direct length-2^%d transform", p, logL);
+  std::unique_ptr<Slab> sl(new Slab);
+  sl->ctx = make_ctx(p);
+  sl->hclass = (9ull * p < (1ull << 32)) ? 9 : (p < (1u << 30)) ? 4 : 2;
+  const uint32_t g = find_nonresidue(p);
+  uint32_t wL = h_powmod(g, (uint64_t)(p - 1) >> logL, p);
+  if (inverse) wL = h_powmod(wL, p - 2, p);
+  const uint32_t wT = h_powmod(wL, 1ull << (logL - logT), p);
+  const uint32_t tinv = h_powmod((uint32_t)((1ull << logT) % p), p - 2, p);
+  if (int rc = upload(&sl->tw, stage_table(wT, logT, sl->ctx))) return rc;
+  if (int rc = upload(&sl->fs, fourstep_table(wL, logT, logC, inverse ? tinv : 1, sl->ctx, (uint64_t)col0))) return rc;
+  *out = sl.get();
+  cx->slabs[key] = std::move(sl);
+  return 0;
+}
+
+static int dev_colpass(Context *cx, uint32_t *d_x, int logL, int logT, long long col0, int cols, uint32_t p, bool inverse,
+                       bool zero_hi, hipStream_t st) {
+  if (logL < 2 || logL > kMaxLog || logT < kMinColLog || logT > kMaxColLog || logT >= logL)
+    return fail(NTTX_ERANGE, "column pass of 2^%d points in a 2^%d transform unsupported", logT, logL);
+  const long long S = 1ll << (logL - logT);
+  int logC = 0; while ((1ll << logC) < cols) ++logC;
+  if (cols < 16 || (1ll << logC) != cols || col0 < 0 || col0 % cols || col0 + cols > S)
+    return fail(NTTX_EINVAL, "slab must be a power-of-two number (>= 16) of columns aligned to its own width");
+  Slab *sl;
+  if (int rc = get_slab(cx, p, logL, logT, col0, logC, inverse, &sl)) return rc;
+  ColArgs C{}; C.in[0] = d_x; C.out[0] = d_x; C.tw = sl->tw; C.fs = sl->fs; C.ctx = sl->ctx; C.logS = logC;
+  C.canon_out = 1; C.nblocks = 1;
+  C.nvalid = (!inverse && zero_hi) ? ((1ll << logT) / 2) * cols : 0;
+  return launch_col(cx, inverse, sl->hclass, logT, C, 1, st);
+}
+
 }  // namespace nttx
 
 // =========================================================================================
@@ -531,6 +632,7 @@ void nttx_shutdown(void) {
   (void)hipSetDevice(g_ctx->device);
   (void)hipDeviceSynchronize();
   g_ctx->plans.clear();
+  g_ctx->slabs.clear();
   g_ctx->prof.destroy();
   for (int i = 0; i < 2; ++i) { if (g_ctx->aux[i]) (void)hipStreamDestroy(g_ctx->aux[i]); if (g_ctx->ev_join[i]) (void)hipEventDestroy(g_ctx->ev_join[i]); }
   if (g_ctx->ev_fork) (void)hipEventDestroy(g_ctx->ev_fork);
@@ -613,6 +715,33 @@ int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int 
   NTTX_ENTER();
   if (!d_a || !d_b || !d_ab || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
   return dev_crt_multiply(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint64_t *)d_ab, n, p, batch, (hipStream_t)stream);
+}
+
+int nttx_dev_crt_residues_u64(const void *d_a, const void *d_b, void *d_res, int n, int prime_mask, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_res || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
+  return dev_crt_residues(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint32_t *)d_res, n, prime_mask, batch, (hipStream_t)stream);
+}
+
+int nttx_dev_crt_recombine_u64(const void *d_r0, const void *d_r1, const void *d_r2, const void *d_r3, void *d_out,
+                               long long count, uint64_t p, void *stream) {
+  NTTX_ENTER();
+  if (!d_r0 || !d_r1 || !d_r2 || !d_r3 || !d_out) return fail(NTTX_EINVAL, "bad arguments");
+  const uint32_t *r[4] = {(const uint32_t *)d_r0, (const uint32_t *)d_r1, (const uint32_t *)d_r2, (const uint32_t *)d_r3};
+  return dev_crt_recombine(cx, r, (uint64_t *)d_out, count, p, (hipStream_t)stream);
+}
+
+int nttx_dev_colpass_u32(void *d_x, int log_len, int log_t, long long col0, int cols, uint32_t p, int inverse, int zero_hi,
+                         void *stream) {
+  NTTX_ENTER();
+  if (!d_x) return fail(NTTX_EINVAL, "bad arguments");
+  return dev_colpass(cx, (uint32_t *)d_x, log_len, log_t, col0, cols, p, inverse != 0, zero_hi != 0, (hipStream_t)stream);
+}
+
+int nttx_crt_prime(int k, uint32_t *prime) {
+  if (k < 0 || k >= 4 || !prime) return fail(NTTX_EINVAL, "CRT prime index out of range");
+  *prime = kCrtPrimes[k];
+  return 0;
 }
 
 static int dev_ntt_impl(Context *cx, uint32_t *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch,

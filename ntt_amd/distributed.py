@@ -1,0 +1,339 @@
+"""Products that span several GPUs: one process per GPU, `torch.distributed` (RCCL on the GPUs)
+for the exchange steps.
+
+Two workloads have a real exchange step:
+
+* `CrtSharded` - the 4-prime CRT product with the primes dealt to ranks (the reference gives every
+  prime a thread, main.cc:306-311 / main_pthread.cc:413-428, and cuts the recombination loop into
+  index ranges, main_pthread.cc:435-465).  Each rank transforms for its own primes, one all-to-all
+  hands every rank all four residues of its slice of the indices, and the recombination
+  (main.cc:323-337) runs on slices.
+* `FourStepSharded` - one product too long for a single pass structure to stay on one GPU: the
+  vector is a T x S matrix split by columns; column passes are local, a transpose (all-to-all)
+  turns column slabs into whole rows, the rows are multiplied locally, and the way back mirrors
+  it: three all-to-alls per product.
+
+Independent products need no exchange at all; they are sharded with `sharding.shard_range`.
+
+The arithmetic is behind an `engine` object.  `HipEngine` (the product) calls the C ABI of
+libnttx.so on device tensors and has no CPU fallback.  The communication is behind a `comm`
+object: `TorchComm` wraps a torch.distributed process group, `ThreadComm` runs the ranks of a
+group as threads of one process (for exercising the multi-rank logic on a single GPU).
+Residues travel as int32 tensors and coefficients as int64 tensors holding the unsigned bit
+patterns (torch has no arithmetic on unsigned 32/64-bit types, and none is needed here).
+"""
+from __future__ import annotations
+
+import threading
+
+from .sharding import shard_range
+
+CRT_PRIME_COUNT = 4
+
+
+# --------------------------------------------------------------------------------------------
+# communication
+# --------------------------------------------------------------------------------------------
+class TorchComm:
+    """A torch.distributed process group (backend "nccl" = RCCL on GPUs, "gloo" on CPU tensors)."""
+
+    def __init__(self, group=None, ranks=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.ranks = list(ranks) if ranks is not None else list(range(dist.get_world_size()))
+        self.world = len(self.ranks)
+        self.rank = self.ranks.index(dist.get_rank())
+
+    def all_to_all(self, send):
+        """send[q] goes to rank q; returns recv with recv[q] = what rank q sent here."""
+        import torch
+        send = send.contiguous()
+        if send.shape[0] != self.world:
+            raise ValueError("leading dimension must equal the group size")
+        recv = torch.empty_like(send)
+        self._dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def all_gather(self, x):
+        import torch
+        x = x.contiguous()
+        out = torch.empty((self.world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        self._dist.all_gather(list(out.unbind(0)), x, group=self.group)
+        return out
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    def split(self, color_of_rank):
+        """Sub-communicators: ranks with equal color_of_rank(rank) form a group.  Collective over
+        the whole communicator (every rank creates every group, as torch.distributed requires)."""
+        colors = {}
+        for r in range(self.world):
+            colors.setdefault(color_of_rank(r), []).append(r)
+        mine = None
+        for color in sorted(colors):
+            members = colors[color]
+            g = self._dist.new_group([self.ranks[m] for m in members])
+            if self.rank in members:
+                mine = TorchComm(g, [self.ranks[m] for m in members])
+        return mine
+
+
+class _ThreadWorld:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class ThreadComm:
+    """Ranks of one process: `ThreadComm.run(world, fn)` starts fn(comm) on `world` threads.
+    Collectives exchange tensor references through shared slots between two barriers."""
+
+    def __init__(self, shared, rank):
+        self._w = shared
+        self.world = shared.world
+        self.rank = rank
+
+    @staticmethod
+    def run(world, fn):
+        shared = _ThreadWorld(world)
+        results, errors = [None] * world, [None] * world
+
+        def body(r):
+            try:
+                results[r] = fn(ThreadComm(shared, r))
+            except BaseException as e:  # noqa: BLE001 - reported to the caller below
+                errors[r] = e
+                shared.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errors:
+            if e is not None and not isinstance(e, threading.BrokenBarrierError):
+                raise e
+        for e in errors:
+            if e is not None:
+                raise e
+        return results
+
+    def _exchange(self, x):
+        w = self._w
+        w.slots[self.rank] = x
+        w.barrier.wait()
+        seen = list(w.slots)
+        w.barrier.wait()
+        return seen
+
+    def all_to_all(self, send):
+        import torch
+        if send.shape[0] != self.world:
+            raise ValueError("leading dimension must equal the group size")
+        if send.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        seen = self._exchange(send.contiguous())
+        return torch.stack([seen[q][self.rank] for q in range(self.world)])
+
+    def all_gather(self, x):
+        import torch
+        if x.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return torch.stack(self._exchange(x.contiguous()))
+
+    def barrier(self):
+        self._w.barrier.wait()
+
+    def split(self, color_of_rank):
+        colors = {}
+        for r in range(self.world):
+            colors.setdefault(color_of_rank(r), []).append(r)
+        # the first member of every group creates the shared state, everyone picks it up
+        created = {}
+        for color, members in colors.items():
+            if members[0] == self.rank:
+                created[color] = _ThreadWorld(len(members))
+        seen = self._exchange(created)
+        my_color = color_of_rank(self.rank)
+        members = colors[my_color]
+        return ThreadComm(seen[members[0]][my_color], members.index(self.rank))
+
+
+# --------------------------------------------------------------------------------------------
+# arithmetic on the GPU (C ABI of libnttx.so)
+# --------------------------------------------------------------------------------------------
+class HipEngine:
+    """Device-tensor front of the C ABI.  Every call raises if the library, the GPU or the
+    tensors' placement is not what the kernels need; there is no other code path."""
+
+    def __init__(self):
+        import torch
+        from . import api
+        self._t = torch
+        self._api = api
+        if not torch.cuda.is_available():
+            raise api.NttxError(-3, "HipEngine needs a GPU")
+
+    def _stream(self):
+        return self._t.cuda.current_stream().cuda_stream
+
+    def _chk(self, x, dtype):
+        if not (x.is_cuda and x.is_contiguous() and x.dtype == dtype):
+            raise ValueError(f"expected a contiguous device tensor of {dtype}")
+
+    @staticmethod
+    def product_len(n):
+        k = 0
+        while (1 << k) < 2 * n:
+            k += 1
+        return 1 << k
+
+    def crt_residues(self, a, b, n, prime_mask):
+        """a, b: [batch][n] int64 -> [primes in mask][batch][len] int32."""
+        t = self._t
+        self._chk(a, t.int64)
+        self._chk(b, t.int64)
+        batch = a.shape[0]
+        nsel = bin(prime_mask).count("1")
+        res = t.empty((nsel, batch, self.product_len(n)), dtype=t.int32, device=a.device)
+        self._api.dev_crt_residues_u64(a.data_ptr(), b.data_ptr(), res.data_ptr(), n, prime_mask, batch, self._stream())
+        return res
+
+    def crt_recombine(self, residues, p):
+        """residues: four int32 tensors of equal shape -> int64 tensor of that shape."""
+        t = self._t
+        for r in residues:
+            self._chk(r, t.int32)
+        out = t.empty(residues[0].shape, dtype=t.int64, device=residues[0].device)
+        self._api.dev_crt_recombine_u64([r.data_ptr() for r in residues], out.data_ptr(), residues[0].numel(), p, self._stream())
+        return out
+
+    def colpass(self, x, log_len, log_t, col0, p, inverse, zero_hi=False):
+        """In place on this rank's [2^log_t][cols] int32 slab."""
+        self._chk(x, self._t.int32)
+        if x.shape[0] != (1 << log_t):
+            raise ValueError("slab must have 2^log_t rows")
+        self._api.dev_colpass_u32(x.data_ptr(), log_len, log_t, col0, x.shape[1], p, inverse, zero_hi, self._stream())
+        return x
+
+    def cyclic_multiply(self, a, b, p):
+        """Row-wise cyclic products of two [rows][len] int32 tensors."""
+        t = self._t
+        self._chk(a, t.int32)
+        self._chk(b, t.int32)
+        c = t.empty_like(a)
+        self._api.dev_cyclic_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.shape[1], p, a.shape[0], self._stream())
+        return c
+
+
+# --------------------------------------------------------------------------------------------
+# 4-prime CRT products, primes dealt to ranks
+# --------------------------------------------------------------------------------------------
+def crt_layout(world):
+    """(prime groups, batch groups): the primes are dealt over min(world, 4) ranks when that
+    divides evenly, and whole copies of that arrangement share the batch."""
+    for gp in (4, 2, 1):
+        if world % gp == 0:
+            return gp, world // gp
+    return 1, world
+
+
+class CrtSharded:
+    """rank r: prime group r % Gp owns the moduli k with k % Gp == r % Gp, batch group r // Gp owns
+    a contiguous share of the products.  The ranks of a batch group exchange residue slices once."""
+
+    def __init__(self, comm, engine):
+        self.comm, self.engine = comm, engine
+        self.gp, self.gb = crt_layout(comm.world)
+        gp = self.gp
+        self.pr, self.br = comm.rank % gp, comm.rank // gp
+        self.own = [k for k in range(CRT_PRIME_COUNT) if k % gp == self.pr]
+        self.mask = sum(1 << k for k in self.own)
+        self.group = comm.split(lambda r: r // gp) if comm.world > 1 else comm
+
+    def batch_range(self, batch):
+        """Products [lo, hi) whose inputs this rank needs (the same for every rank of its batch group)."""
+        return shard_range(batch, self.br, self.gb)
+
+    def multiply(self, a, b, n, p, gather=True):
+        """a, b: [nb][n] int64, this batch group's products.  Returns [nb][2n-1] int64 when gather,
+        else this rank's slice [nb][len/Gp] of the coefficient indices (slice q = indices
+        q*len/Gp .. (q+1)*len/Gp - 1, of which only those below 2n-1 are meaningful)."""
+        gp = self.gp
+        res = self.engine.crt_residues(a, b, n, self.mask)              # [nown][nb][len]
+        nown, nb, length = res.shape
+        if gp == 1:
+            full = self.engine.crt_recombine([res[k] for k in range(CRT_PRIME_COUNT)], p)
+            return full[:, : 2 * n - 1] if gather else full
+        sl = length // gp
+        send = res.view(nown, nb, gp, sl).permute(2, 0, 1, 3).contiguous()   # [dest][nown][nb][sl]
+        recv = self.group.all_to_all(send)                                    # [source][nown][nb][sl]
+        by_prime = [recv[k % gp, k // gp] for k in range(CRT_PRIME_COUNT)]
+        part = self.engine.crt_recombine(by_prime, p)                          # [nb][sl]
+        if not gather:
+            return part
+        parts = self.group.all_gather(part)                                    # [gp][nb][sl]
+        return parts.permute(1, 0, 2).reshape(nb, length)[:, : 2 * n - 1]
+
+
+# --------------------------------------------------------------------------------------------
+# one long product split by columns
+# --------------------------------------------------------------------------------------------
+class FourStepSharded:
+    """Cyclic product of two length-2^log_len vectors over `comm.world` = G ranks (a power of two).
+
+    Layout: element i = j*S + s of a vector sits at (row j, column s) of a T x S matrix
+    (T = 2^log_t); rank g holds columns g*S/G .. (g+1)*S/G - 1 as a dense [T][S/G] int32 slab, for
+    inputs and for the result alike.  `slab_of` / `place_slab` convert from and to whole vectors."""
+
+    def __init__(self, comm, engine, log_len, p, log_t=None):
+        g = comm.world
+        if g & (g - 1):
+            raise ValueError("the number of ranks must be a power of two")
+        if log_t is None:
+            log_t = min(9, log_len // 2)
+        self.comm, self.engine, self.p = comm, engine, p
+        self.log_len, self.log_t = log_len, log_t
+        self.T, self.S = 1 << log_t, 1 << (log_len - log_t)
+        if self.T % g or self.S % g or self.S // g < 16:
+            raise ValueError("need G | T and at least 16 columns per rank")
+        self.cols = self.S // g
+        self.col0 = comm.rank * self.cols
+        self.rows = self.T // g
+
+    def slab_of(self, vec):
+        """This rank's slab of a whole length-2^log_len vector (testing / data loading)."""
+        return vec.view(self.T, self.S)[:, self.col0: self.col0 + self.cols].contiguous()
+
+    def place_slab(self, vec, slab):
+        vec.view(self.T, self.S)[:, self.col0: self.col0 + self.cols] = slab
+
+    def _to_rows(self, x):
+        g = self.comm.world
+        if g == 1:
+            return x
+        y = self.comm.all_to_all(x.view(g, self.rows, self.cols))          # [source][rows][cols]
+        return y.permute(1, 0, 2).reshape(self.rows, self.S)
+
+    def _to_slab(self, y):
+        g = self.comm.world
+        if g == 1:
+            return y
+        z = y.view(self.rows, g, self.cols).permute(1, 0, 2).contiguous()    # [dest][rows][cols]
+        return self.comm.all_to_all(z).view(self.T, self.cols)
+
+    def multiply(self, xa, xb, zero_hi=False):
+        """xa, xb: this rank's slabs (overwritten).  zero_hi: both inputs are zero from index
+        2^(log_len-1) on (a linear product), so the upper half of the rows is not read.
+        Returns this rank's slab of the product."""
+        e, L, t, p = self.engine, self.log_len, self.log_t, self.p
+        e.colpass(xa, L, t, self.col0, p, False, zero_hi)
+        e.colpass(xb, L, t, self.col0, p, False, zero_hi)
+        ya, yb = self._to_rows(xa), self._to_rows(xb)
+        yc = e.cyclic_multiply(ya.contiguous(), yb.contiguous(), p)
+        xc = self._to_slab(yc).contiguous()
+        e.colpass(xc, L, t, self.col0, p, True)
+        return xc

@@ -1,0 +1,163 @@
+"""GPU parity of the multi-process building blocks (slab column pass, per-prime residues,
+slice recombination) against the oracle-backed CPU engine, and of the two exchange-step
+workloads run with several in-process ranks on the one GPU of the test box.  All calls go
+through the C ABI (ntt_amd.distributed.HipEngine -> ntt_amd.api -> libnttx.so)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.cpu_engine import CRT_PRIMES, OracleEngine
+
+pytestmark = pytest.mark.gpu
+
+P64 = 1337006139375617     # 19 * 2^46 + 1, the modulus of harness id 4
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("p,log_len,log_t,col0,cols,zero_hi", [
+    (469762049, 12, 6, 0, 64, False),       # the whole matrix as one slab
+    (469762049, 13, 6, 32, 32, False),
+    (998244353, 14, 7, 64, 16, True),
+    (1224736769, 15, 8, 96, 32, True),
+    (1004535809, 16, 9, 0, 64, False),
+    (469762049, 17, 10, 112, 16, True),
+])
+def test_colpass_matches_cpu_engine(nttx, oracle, p, log_len, log_t, col0, cols, zero_hi):
+    from ntt_amd.distributed import HipEngine
+    T = 1 << log_t
+    x = oracle.fill_random(T * cols, 5, p).astype(np.uint32).reshape(T, cols)
+    if zero_hi:
+        x[T // 2:] = 0
+    want = torch.from_numpy(x.view(np.int32).copy())
+    OracleEngine(oracle).colpass(want, log_len, log_t, col0, p, False, zero_hi)
+    got = _dev(x.view(np.int32))
+    HipEngine().colpass(got, log_len, log_t, col0, p, False, zero_hi)
+    assert torch.equal(got.cpu(), want)
+    # inverse pass on the forward output gives the input back (the slab factors and 1/T cancel)
+    back = got.clone()
+    HipEngine().colpass(back, log_len, log_t, col0, p, True)
+    assert np.array_equal(back.cpu().numpy().view(np.uint32), x)
+    want_inv = want.clone()
+    OracleEngine(oracle).colpass(want_inv, log_len, log_t, col0, p, True)
+    assert np.array_equal(want_inv.numpy().view(np.uint32), x)
+
+
+def test_colpass_rejects_bad_slabs(nttx):
+    from ntt_amd.distributed import HipEngine
+    e = HipEngine()
+    x = torch.zeros((64, 24), dtype=torch.int32, device="cuda")
+    with pytest.raises(nttx.NttxError):
+        e.colpass(x, 12, 6, 0, 469762049, False)          # 24 columns: not a power of two
+    x = torch.zeros((64, 32), dtype=torch.int32, device="cuda")
+    with pytest.raises(nttx.NttxError):
+        e.colpass(x, 12, 6, 48, 469762049, False)         # not aligned to its own width
+    with pytest.raises(nttx.NttxError):
+        e.colpass(x, 12, 6, 64, 469762049, False)         # beyond the S = 64 columns
+    with pytest.raises(nttx.NttxError):
+        e.colpass(x, 12, 6, 0, 7340033 * 3, False)        # not a prime with the needed root
+
+
+@pytest.mark.parametrize("mask", (1, 2, 4, 8, 5, 10, 15))
+def test_crt_residues_and_recombine(nttx, oracle, mask):
+    from ntt_amd.distributed import HipEngine
+    n, batch = 300, 3
+    a = np.stack([oracle.fill_random(n, 20 + i, P64) for i in range(batch)]).astype(np.uint64)
+    b = np.stack([oracle.fill_random(n, 30 + i, P64) for i in range(batch)]).astype(np.uint64)
+    ta, tb = torch.from_numpy(a.view(np.int64)), torch.from_numpy(b.view(np.int64))
+    want = OracleEngine(oracle).crt_residues(ta, tb, n, mask)
+    got = HipEngine().crt_residues(ta.cuda(), tb.cuda(), n, mask)
+    assert torch.equal(got.cpu(), want)
+    assert [nttx.crt_prime(k) for k in range(4)] == list(CRT_PRIMES)
+    if mask == 15:
+        out = HipEngine().crt_recombine([got[k].contiguous() for k in range(4)], P64)
+        full = out.cpu().numpy().view(np.uint64)
+        for i in range(batch):
+            assert np.array_equal(full[i, : 2 * n - 1], oracle.poly_multiply_crt(a[i], b[i], P64))
+        # a slice of the indices recombines to the same values
+        sl = [got[k][:, 128:384].contiguous() for k in range(4)]
+        part = HipEngine().crt_recombine(sl, P64).cpu().numpy().view(np.uint64)
+        assert np.array_equal(part, full[:, 128:384])
+
+
+@pytest.mark.parametrize("world", (1, 2, 4, 8))
+def test_crt_sharded_in_process_ranks(nttx, oracle, world):
+    from ntt_amd.distributed import CrtSharded, HipEngine, ThreadComm
+    n, batch = 1000, 4
+    a = np.stack([oracle.fill_random(n, 120 + i, P64) for i in range(batch)]).astype(np.uint64)
+    b = np.stack([oracle.fill_random(n, 130 + i, P64) for i in range(batch)]).astype(np.uint64)
+    want = np.stack([oracle.poly_multiply_crt(a[i], b[i], P64) for i in range(batch)])
+
+    def body(comm):
+        torch.cuda.set_device(0)
+        sh = CrtSharded(comm, HipEngine())
+        lo, hi = sh.batch_range(batch)
+        out = sh.multiply(_dev(a[lo:hi].view(np.int64)), _dev(b[lo:hi].view(np.int64)), n, P64)
+        return lo, hi, out.cpu().numpy().view(np.uint64)
+
+    for lo, hi, out in ThreadComm.run(world, body):
+        assert np.array_equal(out, want[lo:hi])
+
+
+@pytest.mark.parametrize("p,log_len,log_t,world,linear", [
+    (469762049, 14, 6, 2, True),
+    (998244353, 16, 8, 4, False),
+    (1224736769, 17, 9, 8, True),
+    (469762049, 16, 7, 1, True),
+])
+def test_fourstep_sharded_vs_oracle(nttx, oracle, p, log_len, log_t, world, linear):
+    from ntt_amd.distributed import FourStepSharded, HipEngine, ThreadComm
+    L = 1 << log_len
+    a, b = oracle.fill_random(L, 41, p).astype(np.uint32), oracle.fill_random(L, 42, p).astype(np.uint32)
+    if linear:
+        a[L // 2:] = 0
+        b[L // 2:] = 0
+    want = oracle.ntt_compute(a, b, p)
+
+    def body(comm):
+        torch.cuda.set_device(0)
+        fs = FourStepSharded(comm, HipEngine(), log_len, p, log_t=log_t)
+        xa, xb = fs.slab_of(_dev(a.view(np.int32))), fs.slab_of(_dev(b.view(np.int32)))
+        return fs.col0, fs.cols, fs.multiply(xa, xb, zero_hi=linear).cpu().numpy().view(np.uint32)
+
+    full = np.zeros(L, dtype=np.uint32)
+    for col0, cols, slab in ThreadComm.run(world, body):
+        full.reshape(1 << log_t, -1)[:, col0: col0 + cols] = slab
+    assert np.array_equal(full, want)
+
+
+def test_fourstep_sharded_large_vs_single_gpu(nttx, oracle):
+    """Length 2^22 over 4 in-process ranks equals the single-GPU three-pass product bit for bit."""
+    from ntt_amd.distributed import FourStepSharded, HipEngine, ThreadComm
+    p, log_len = 469762049, 22
+    L = 1 << log_len
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    a = torch.randint(0, p, (L,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    b = torch.randint(0, p, (L,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    a[L // 2:] = 0
+    b[L // 2:] = 0
+    ref = torch.empty_like(a)
+    nttx.dev_cyclic_multiply_u32(a.data_ptr(), b.data_ptr(), ref.data_ptr(), L, p, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    full = torch.zeros_like(a)
+
+    def body(comm):
+        torch.cuda.set_device(0)
+        fs = FourStepSharded(comm, HipEngine(), log_len, p)
+        xc = fs.multiply(fs.slab_of(a), fs.slab_of(b), zero_hi=True)
+        fs.place_slab(full, xc)
+        torch.cuda.synchronize()
+        return None
+
+    ThreadComm.run(4, body)
+    assert torch.equal(full, ref)
+    # spot-check against the definition at a few indices (exact integer arithmetic on the host)
+    ah, bh = a.cpu().numpy().view(np.uint32).astype(np.uint64), b.cpu().numpy().view(np.uint32).astype(np.uint64)
+    fh = full.cpu().numpy().view(np.uint32)
+    for i in (0, 1, 12345, L // 2 - 1, L // 2, L - 2):
+        lo, hi = max(0, i - (L // 2 - 1)), min(i, L // 2 - 1)
+        terms = ah[lo: hi + 1] * bh[i - hi: i - lo + 1][::-1] % np.uint64(p)     # each product < 2^58
+        assert int(terms.sum(dtype=np.uint64)) % p == int(fh[i])                # at most 2^21 terms < 2^29
