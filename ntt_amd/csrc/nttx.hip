@@ -85,7 +85,13 @@ constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 
 static int decompose(int k, int lt[3]) {
   if (k <= kMaxRowLog) { lt[0] = k; return 1; }
-  if (k <= kMaxColLog + kMaxRowLog) { lt[0] = k / 2; lt[1] = k - lt[0]; return 2; }
+  if (k <= kMaxColLog + kMaxRowLog) {
+    lt[0] = k / 2;
+    static const int col_bias = [] { const char *e = getenv("NTTX_COL_BIAS"); return e ? atoi(e) : 0; }();   // experiments
+    if (lt[0] + col_bias >= kMinColLog && lt[0] + col_bias <= kMaxColLog && k - lt[0] - col_bias <= kMaxRowLog && k - lt[0] - col_bias >= 1) lt[0] += col_bias;
+    lt[1] = k - lt[0];
+    return 2;
+  }
   int row = (k + 2) / 3; if (row > kMaxRowLog) row = kMaxRowLog;
   int rem = k - row;
   lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;

@@ -43,7 +43,7 @@ fetch, write, sq, sq2 = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), pmc("
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 kind = {"col_kernel<9, false": "col_fwd", "row_mul9_kernel": "row_mul", "col_kernel<9, true": "col_inv"}
 traffic = {}
-lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 5 --warmup 2 --no-cpu` (batch 256, L = 2^18, p = 469762049)", "",
+lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 200 --warmup 50 --no-cpu` (batch 256, L = 2^18, p = 469762049)", "",
          "Kernel trace (`rocprofv3 --kernel-trace --stats`):", "",
          "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
 for n, c, a, mn, mx, pct in stats:
