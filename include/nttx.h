@@ -32,6 +32,7 @@ extern "C" {
 /* Which arithmetic path a (p, n) pair takes. */
 #define NTTX_PATH_DIRECT32 0 /* one NTT modulo p itself: p < 2^31 prime, 2^k | p-1 (monttry2.cpp get_result) */
 #define NTTX_PATH_CRT4 1     /* four 32-bit NTT primes + CRT (main.cc:245-338) */
+#define NTTX_PATH_DIRECT64 2 /* one NTT modulo p itself on 64-bit lanes: 2^31 <= p < 2^62 prime, 2^k | p-1 */
 
 /* Select the GPU of this process and build the context (one process per GPU).
  * No counterpart in the reference (CPU-only program start-up, main.cc:230-270 builds
@@ -52,6 +53,12 @@ int nttx_poly_multiply_i32(const int32_t *a, const int32_t *b, int32_t *ab, int 
  * main_pthread.cc:386-475 (residue split, 4 x ntt_compute_omp, CRT, mod p).
  * Takes the direct single-prime path when p allows it, the 4-prime CRT path otherwise. */
 int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
+
+/* One transform modulo p itself on 64-bit lanes (Montgomery radix 2^64) for NTT-friendly moduli
+ * beyond 32 bits, e.g. 19*2^46+1 of harness id 4: the single-prime structure of get_result
+ * (monttry2.cpp:319-343), which the reference cannot apply there (its int p overflows) and
+ * replaces by main.cc's four primes + CRT.  Coefficients are identical to the CRT route. */
+int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
 
 /* Force the 4-prime CRT path (main.cc:286-338) whatever p is. */
 int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
@@ -93,6 +100,16 @@ int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int 
 int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch,
                               void *stream);
 
+/* 64-bit-lane counterpart of nttx_dev_poly_multiply_u32: d_a, d_b, d_c are zero-padded
+ * [batch][len] u64 arrays, len the smallest power of two >= 2n; inputs below p. */
+int nttx_dev_direct_multiply_u64(const void *d_a, const void *d_b, void *d_c, int n, uint64_t p, int batch,
+                                 void *stream);
+
+/* In-place batched 64-bit-lane transform, [batch][len] u64, natural order in, bit-reversed order
+ * out, root 3^((p-1)/len) (or its inverse), no scaling (ntt_iter_barrett main.cc:143-182 without
+ * its final permutation). */
+int nttx_dev_ntt_u64(void *d_x, int len, uint64_t p, int inverse, int batch, void *stream);
+
 /* In-place batched transform on device memory, [batch][len]; bit_reversed_out != 0 skips
  * the final permutation (forward output stays in bit-reversed order). */
 int nttx_dev_ntt_u32(void *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch, void *stream);
@@ -132,6 +149,7 @@ int nttx_dev_colpass_u32(void *d_x, int log_len, int log_t, long long col0, int 
 
 /* Pre-size the internal workspace so that later device-resident calls allocate nothing. */
 int nttx_reserve(int len, int batch, int nprimes);
+int nttx_reserve_u64(int len, int batch);   /* same for the 64-bit-lane direct path */
 
 /* Per-kernel device timing with HIP events recorded on the launch stream around every
  * kernel of the path (no counterpart in the reference, which times the whole block with

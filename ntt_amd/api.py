@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NTTX_LIB") or os.path.join(_HERE, "csrc", "libnttx.so")  # NTTX_LIB: experiment builds
 
 CRT_PRIMES = (469762049, 998244353, 1004535809, 1224736769)  # main.cc:245-248
-PATH_DIRECT32, PATH_CRT4 = 0, 1
+PATH_DIRECT32, PATH_CRT4, PATH_DIRECT64 = 0, 1, 2
 
 _u32p = C.POINTER(C.c_uint32)
 _u64p = C.POINTER(C.c_uint64)
@@ -26,6 +26,7 @@ _SIGS = [
     ("nttx_path_for", C.c_int, [C.c_uint64, C.c_int]),
     ("nttx_poly_multiply_i32", C.c_int, [_i32p, _i32p, _i32p, C.c_int, C.c_int32]),
     ("nttx_poly_multiply_u64", C.c_int, [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]),
+    ("nttx_poly_multiply_direct_u64", C.c_int, [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]),
     ("nttx_poly_multiply_crt_u64", C.c_int, [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]),
     ("nttx_poly_multiply_batch_u32", C.c_int, [_u32p, _u32p, _u32p, C.c_int, C.c_uint32, C.c_int]),
     ("nttx_ntt_u32", C.c_int, [_u32p, C.c_int, C.c_uint32, C.c_int]),
@@ -39,7 +40,10 @@ _SIGS = [
     ("nttx_dev_crt_residues_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_dev_crt_recombine_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint64, C.c_void_p]),
     ("nttx_dev_colpass_u32", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    ("nttx_dev_direct_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
+    ("nttx_dev_ntt_u64", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_reserve", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("nttx_reserve_u64", C.c_int, [C.c_int, C.c_int]),
     ("nttx_profile_enable", C.c_int, [C.c_int]),
     ("nttx_profile_reset", C.c_int, []),
     ("nttx_profile_read", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
@@ -143,6 +147,14 @@ def poly_multiply_crt(a, b, n: int, p: int):
     return ab
 
 
+def poly_multiply_direct64(a, b, n: int, p: int):
+    """One 64-bit-lane transform modulo p itself (NTT-friendly p between 2^31 and 2^62)."""
+    a, b = _arr(a, np.uint64)[:n], _arr(b, np.uint64)[:n]
+    ab = np.zeros(max(2 * n - 1, 0), dtype=np.uint64)
+    _check(lib().nttx_poly_multiply_direct_u64(a.ctypes.data_as(_u64p), b.ctypes.data_as(_u64p), ab.ctypes.data_as(_u64p), n, p))
+    return ab
+
+
 def poly_multiply_batch(a, b, p: int):
     """a, b: [batch][n] uint32 -> [batch][2n-1]."""
     a, b = _arr(a, np.uint32), _arr(b, np.uint32)
@@ -188,6 +200,19 @@ def dev_poly_multiply_u32(d_a: int, d_b: int, d_c: int, n: int, p: int, batch: i
 
 def dev_crt_multiply_u64(d_a: int, d_b: int, d_ab: int, n: int, p: int, batch: int, stream: int = 0):
     _check(lib().nttx_dev_crt_multiply_u64(d_a, d_b, d_ab, n, p, batch, stream))
+
+
+def dev_direct_multiply_u64(d_a: int, d_b: int, d_c: int, n: int, p: int, batch: int, stream: int = 0):
+    """Linear product of zero-padded [batch][len] u64 device arrays on the 64-bit-lane path."""
+    _check(lib().nttx_dev_direct_multiply_u64(d_a, d_b, d_c, n, p, batch, stream))
+
+
+def dev_ntt_u64(d_x: int, length: int, p: int, invert: bool, batch: int, stream: int = 0):
+    _check(lib().nttx_dev_ntt_u64(d_x, length, p, int(bool(invert)), batch, stream))
+
+
+def reserve_u64(length: int, batch: int):
+    _check(lib().nttx_reserve_u64(length, batch))
 
 
 def dev_ntt_u32(d_x: int, length: int, p: int, invert: bool, bit_reversed_out: bool, batch: int, stream: int = 0):

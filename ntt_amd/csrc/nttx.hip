@@ -22,6 +22,7 @@
 #include "../../include/nttx.h"
 #include "nttx_arith.hpp"
 #include "nttx_kernels.hpp"
+#include "nttx64.hpp"
 
 namespace nttx {
 
@@ -142,6 +143,7 @@ struct Context {
   DevBuf pa, pb, pc;        // padded residues / product [nprimes][batch][len]
   DevBuf outb;              // compacted output staged for the copy back
   DevBuf tmp;               // transform API scratch
+  Engine64 *e64 = nullptr;  // plans and workspace of the 64-bit-lane direct path
   hipStream_t aux[2] = {nullptr, nullptr};   // side streams for pipelining launch groups
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
@@ -601,6 +603,12 @@ static int dev_colpass(Context *cx, uint32_t *d_x, int logL, int logT, long long
   return launch_col(cx, inverse, sl->hclass, logT, C, 1, st);
 }
 
+// ---- 64-bit-lane direct path (nttx64.hip) ------------------------------------------------
+static void prof64_begin(void *self, int kind, hipStream_t st) { static_cast<Profiler *>(self)->begin(kind, st); }
+static void prof64_end(void *self, hipStream_t st) { static_cast<Profiler *>(self)->end(st); }
+static ProfHook64 prof_hook(Context *cx) { return ProfHook64{&cx->prof, prof64_begin, prof64_end}; }
+static int fail_from64(int rc) { return rc < 0 ? fail(rc, "%s", engine64_error()) : rc; }
+
 }  // namespace nttx
 
 // =========================================================================================
@@ -628,6 +636,7 @@ int nttx_init(int device) {
   HIPCHK(hipSetDevice(device));
   g_ctx = new Context;
   g_ctx->device = device;
+  g_ctx->e64 = engine64_create();
   (void)crt_const();
   return 0;
 }
@@ -639,6 +648,7 @@ void nttx_shutdown(void) {
   (void)hipDeviceSynchronize();
   g_ctx->plans.clear();
   g_ctx->slabs.clear();
+  engine64_destroy(g_ctx->e64);
   g_ctx->prof.destroy();
   for (int i = 0; i < 2; ++i) { if (g_ctx->aux[i]) (void)hipStreamDestroy(g_ctx->aux[i]); if (g_ctx->ev_join[i]) (void)hipEventDestroy(g_ctx->ev_join[i]); }
   if (g_ctx->ev_fork) (void)hipEventDestroy(g_ctx->ev_fork);
@@ -650,7 +660,8 @@ void nttx_shutdown(void) {
 
 int nttx_path_for(uint64_t p, int n) {
   if (n <= 0 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
-  return direct_ok(p, log2_ceil_len(n)) ? NTTX_PATH_DIRECT32 : NTTX_PATH_CRT4;
+  const int k = log2_ceil_len(n);
+  return direct_ok(p, k) ? NTTX_PATH_DIRECT32 : engine64_ok(p, k) ? NTTX_PATH_DIRECT64 : NTTX_PATH_CRT4;
 }
 
 int nttx_plan_info(int len, int *logt) {
@@ -886,9 +897,60 @@ int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *a
   return 0;
 }
 
+int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
+  if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
+  NTTX_ENTER();
+  const int logL = log2_ceil_len(n);
+  if (!engine64_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %llu has no direct 64-bit transform of length 2^%d", (unsigned long long)p, logL);
+  const long long len = 1ll << logL;
+  const size_t raw = (size_t)n * 8, vec = (size_t)len * 8;
+  const int nout = 2 * n - 1;
+  if (int rc = cx->in_a.ensure(raw)) return rc;
+  if (int rc = cx->in_b.ensure(raw)) return rc;
+  if (int rc = cx->pa.ensure(vec)) return rc;
+  if (int rc = cx->pb.ensure(vec)) return rc;
+  if (int rc = cx->pc.ensure(vec)) return rc;
+  if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
+  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  const ProfHook64 ph = prof_hook(cx);
+  if (int rc = fail_from64(engine64_pad(cx->e64, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->pa.as<uint64_t>(),
+                                        cx->pb.as<uint64_t>(), n, logL, p, 1, nullptr))) return rc;
+  if (int rc = fail_from64(engine64_cyclic_multiply(cx->e64, cx->pa.as<uint64_t>(), cx->pb.as<uint64_t>(), cx->pc.as<uint64_t>(),
+                                                    logL, p, 1, n, nullptr, &ph))) return rc;
+  if (int rc = fail_from64(engine64_unpad(cx->pc.as<uint64_t>(), cx->outb.as<uint64_t>(), nout, logL, 1, nullptr))) return rc;
+  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nttx_dev_direct_multiply_u64(const void *d_a, const void *d_b, void *d_c, int n, uint64_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_c || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
+  const ProfHook64 ph = prof_hook(cx);
+  return fail_from64(engine64_cyclic_multiply(cx->e64, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint64_t *)d_c,
+                                              log2_ceil_len(n), p, batch, n, (hipStream_t)stream, &ph));
+}
+
+int nttx_dev_ntt_u64(void *d_x, int len, uint64_t p, int inverse, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_x || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
+  int k = 0; while ((1ll << k) < len) ++k;
+  const ProfHook64 ph = prof_hook(cx);
+  return fail_from64(engine64_forward(cx->e64, (uint64_t *)d_x, k, p, inverse, batch, (hipStream_t)stream, &ph));
+}
+
+int nttx_reserve_u64(int len, int batch) {
+  NTTX_ENTER();
+  if (len < 2 || (len & (len - 1)) || batch < 1) return fail(NTTX_EINVAL, "bad arguments");
+  int k = 0; while ((1ll << k) < len) ++k;
+  return fail_from64(engine64_reserve(cx->e64, k, batch));
+}
+
 int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
   if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
-  if (nttx_path_for(p, n) != NTTX_PATH_DIRECT32) return nttx_poly_multiply_crt_u64(a, b, ab, n, p);
+  const int path = nttx_path_for(p, n);
+  if (path == NTTX_PATH_DIRECT64) return nttx_poly_multiply_direct_u64(a, b, ab, n, p);
+  if (path != NTTX_PATH_DIRECT32) return nttx_poly_multiply_crt_u64(a, b, ab, n, p);
   NTTX_ENTER();
   // direct path on 32-bit lanes: reduce the u64 coefficients mod p on the device (one modulus)
   const int logL = log2_ceil_len(n);

@@ -1,0 +1,321 @@
+// Host side of the 64-bit-lane direct path: plans (decomposition + Montgomery tables, R = 2^64),
+// workspace and kernel launches for nttx_kernels64.hpp.  The orchestration is that of the
+// single-prime product get_result (monttry2.cpp:319-343: forward a, forward b, pointwise,
+// inverse, scale by n^-1) on a modulus the reference can only reach through four 32-bit
+// primes and CRT (main.cc:286-338).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/nttx.h"
+#include "nttx64.hpp"
+#include "nttx_arith.hpp"
+#include "nttx_kernels64.hpp"
+
+namespace nttx {
+
+static thread_local std::string g_err64;
+static int fail64(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err64 = buf;
+  return code;
+}
+const char *engine64_error() { return g_err64.c_str(); }
+#define HIPCHK64(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+  return fail64(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+constexpr int kMaxRow64 = 11, kMinCol64 = 6, kMaxCol64 = 9, kMaxLog64 = 29;
+
+int engine64_decompose(int k, int lt[3]) {
+  if (k <= kMaxRow64) { lt[0] = k; return 1; }
+  if (k <= kMaxCol64 + kMaxRow64) { lt[0] = std::min(kMaxCol64, k / 2); lt[1] = k - lt[0]; return 2; }
+  int row = std::max((k + 2) / 3, k - 2 * kMaxCol64);
+  if (row > kMaxRow64) row = kMaxRow64;
+  const int rem = k - row;
+  lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
+  return 3;
+}
+
+struct Plan64 {
+  uint64_t p = 0; int logL = 0; bool conj = false; bool safe = false, plo1 = false;
+  PrimeArgs64 ctx{};
+  int npass = 0; int lt[3] = {0, 0, 0};
+  uint64_t *tw_fwd[3] = {nullptr, nullptr, nullptr}, *tw_inv[3] = {nullptr, nullptr, nullptr};
+  uint64_t *fs_fwd[2] = {nullptr, nullptr}, *fs_inv[2] = {nullptr, nullptr};
+  uint64_t pre_single = 0;   // n^-1 R^2 mod p
+  ~Plan64() {
+    for (auto q : tw_fwd) if (q) (void)hipFree(q);
+    for (auto q : tw_inv) if (q) (void)hipFree(q);
+    for (auto q : fs_fwd) if (q) (void)hipFree(q);
+    for (auto q : fs_inv) if (q) (void)hipFree(q);
+  }
+};
+
+struct Buf64 {
+  void *ptr = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (ptr) { HIPCHK64(hipFree(ptr)); ptr = nullptr; cap = 0; }
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    HIPCHK64(hipMalloc(&ptr, want));
+    cap = want;
+    return 0;
+  }
+  ~Buf64() { if (ptr) (void)hipFree(ptr); }
+};
+
+struct Engine64 {
+  std::map<std::tuple<uint64_t, int, bool>, std::unique_ptr<Plan64>> plans;
+  Buf64 wa, wb;
+};
+
+Engine64 *engine64_create() { return new Engine64; }
+void engine64_destroy(Engine64 *e) { delete e; }
+
+// ---- host arithmetic ---------------------------------------------------------------------
+static uint64_t find_nonresidue64(uint64_t p) {   // the reference's root 3 first (main.cc:241)
+  const uint64_t cand[] = {3, 2, 5, 6, 7, 10, 11, 13, 14, 15, 17, 19, 21, 22, 23, 26, 29, 31, 37, 41, 43, 47};
+  for (uint64_t g : cand) if (g % p && h_powmod64(g, (p - 1) / 2, p) == p - 1) return g;
+  for (uint64_t g = 48; g < 100000; ++g) if (h_powmod64(g, (p - 1) / 2, p) == p - 1) return g;
+  return 0;
+}
+
+bool engine64_ok(uint64_t p, int logL) {
+  if (p < (1ull << 31) || p >= (1ull << 62) || (p & 1) == 0) return false;
+  if (logL < 1 || logL > kMaxLog64) return false;
+  if (((p - 1) & ((1ull << logL) - 1)) != 0) return false;
+  if (!is_prime_u64(p)) return false;
+  return find_nonresidue64(p) != 0;
+}
+
+struct HostMont64 {
+  uint64_t p, npinv, one, r2;
+  uint64_t mul(uint64_t a, uint64_t b) const { return mont_mul64(a, b, p, npinv); }   // canonical
+  uint64_t to(uint64_t x) const { return mul(x % p, r2); }
+};
+
+static inline uint32_t bitrev64(uint32_t x, int bits) {
+  uint32_t r = 0;
+  for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+
+// tab[h + j] = w^(j * T/(2h)), Montgomery form, h = 1, 2, ..., T/2
+static std::vector<uint64_t> stage_table64(uint64_t w, int logT, const HostMont64 &M) {
+  const int T = 1 << logT;
+  std::vector<uint64_t> tab(std::max(T, 2), 0);
+  for (int h = 1; h < T; h <<= 1) {
+    const uint64_t step = M.to(h_powmod64(w, (uint64_t)(T / (2 * h)), M.p));
+    uint64_t cur = M.one;
+    for (int j = 0; j < h; ++j) { tab[h + j] = cur; cur = M.mul(cur, step); }
+  }
+  return tab;
+}
+
+// tab[j*S + s] = extra * wN^(s * bitrev_T(j)), Montgomery form
+static std::vector<uint64_t> fourstep_table64(uint64_t wN, int logT, int logS, uint64_t extra, const HostMont64 &M) {
+  const size_t T = (size_t)1 << logT, S = (size_t)1 << logS;
+  std::vector<uint64_t> tab(T * S);
+  const uint64_t e0 = M.to(extra);
+  for (size_t j = 0; j < T; ++j) {
+    const uint64_t step = M.to(h_powmod64(wN, bitrev64((uint32_t)j, logT), M.p));
+    uint64_t cur = e0;
+    uint64_t *row = &tab[j * S];
+    for (size_t s = 0; s < S; ++s) { row[s] = cur; cur = M.mul(cur, step); }
+  }
+  return tab;
+}
+
+static int upload64(uint64_t **dst, const std::vector<uint64_t> &h) {
+  HIPCHK64(hipMalloc((void **)dst, h.size() * sizeof(uint64_t)));
+  HIPCHK64(hipMemcpy(*dst, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int get_plan64(Engine64 *e, uint64_t p, int logL, bool conj, Plan64 **out) {
+  auto key = std::make_tuple(p, logL, conj);
+  auto it = e->plans.find(key);
+  if (it != e->plans.end()) { *out = it->second.get(); return 0; }
+  if (!engine64_ok(p, logL))
+    return fail64(NTTX_EINVAL, "modulus %llu does not support a direct 64-bit length-2^%d transform", (unsigned long long)p, logL);
+  std::unique_ptr<Plan64> pl(new Plan64);
+  pl->p = p; pl->logL = logL; pl->conj = conj;
+  pl->safe = p >= (1ull << 51);
+  pl->plo1 = (uint32_t)p == 1u;
+  const PrimeCtx64 c = make_ctx64(p);
+  HostMont64 M{p, c.npinv, (uint64_t)((((unsigned __int128)1) << 64) % p), c.r2};
+  pl->ctx = PrimeArgs64{p, c.npinv, M.one, M.r2};
+  pl->npass = engine64_decompose(logL, pl->lt);
+  const uint64_t g = find_nonresidue64(p);
+  uint64_t wL = h_powmod64(g, (p - 1) >> logL, p);                 // primitive 2^logL-th root (main.cc:156)
+  if (conj) wL = h_powmod64(wL, p - 2, p);                         // main.cc:157
+  const uint64_t wLi = h_powmod64(wL, p - 2, p);
+  const uint64_t Lfull = 1ull << logL;
+  const uint64_t ninv = h_powmod64(Lfull % p, p - 2, p);           // main.cc:204
+  pl->pre_single = M.mul(M.to(ninv), M.r2);                        // n^-1 R^2 mod p
+  int logN = logL;
+  for (int lv = 0; lv < pl->npass; ++lv) {
+    const int lt = pl->lt[lv];
+    const uint64_t wN = h_powmod64(wL, Lfull >> logN, p), wNi = h_powmod64(wLi, Lfull >> logN, p);
+    const uint64_t wT = h_powmod64(wN, (1ull << logN) >> lt, p), wTi = h_powmod64(wNi, (1ull << logN) >> lt, p);
+    if (int rc = upload64(&pl->tw_fwd[lv], stage_table64(wT, lt, M))) return rc;
+    if (int rc = upload64(&pl->tw_inv[lv], stage_table64(wTi, lt, M))) return rc;
+    if (lv < pl->npass - 1) {
+      const int logS = logN - lt;
+      if (int rc = upload64(&pl->fs_fwd[lv], fourstep_table64(wN, lt, logS, 1, M))) return rc;
+      if (int rc = upload64(&pl->fs_inv[lv], fourstep_table64(wNi, lt, logS, lv == 0 ? ninv : 1, M))) return rc;
+      logN = logS;
+    }
+  }
+  *out = pl.get();
+  e->plans[key] = std::move(pl);
+  return 0;
+}
+
+// ---- launches ------------------------------------------------------------------------------
+static int grid_for64(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
+
+template <int MODE, bool SAFE, bool PLO1>
+static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
+#define NTTX_ROW64_CASE(K) case K: { \
+    using Lyt = RowLayout64<K>; \
+    const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
+    hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, 4096)), dim3(256), 0, st, A); break; }
+  switch (logT) {
+    NTTX_ROW64_CASE(1) NTTX_ROW64_CASE(2) NTTX_ROW64_CASE(3) NTTX_ROW64_CASE(4) NTTX_ROW64_CASE(5) NTTX_ROW64_CASE(6)
+    NTTX_ROW64_CASE(7) NTTX_ROW64_CASE(8) NTTX_ROW64_CASE(9) NTTX_ROW64_CASE(10) NTTX_ROW64_CASE(11)
+    default: return fail64(NTTX_ERANGE, "row pass of 2^%d points unsupported", logT);
+  }
+#undef NTTX_ROW64_CASE
+  HIPCHK64(hipGetLastError());
+  return 0;
+}
+template <int MODE>
+static int launch_row64_m(const Plan64 *pl, int logT, const RowArgs64 &A, hipStream_t st) {
+  if (pl->safe) return pl->plo1 ? launch_row64_t<MODE, true, true>(logT, A, st) : launch_row64_t<MODE, true, false>(logT, A, st);
+  return pl->plo1 ? launch_row64_t<MODE, false, true>(logT, A, st) : launch_row64_t<MODE, false, false>(logT, A, st);
+}
+static int launch_row64(const Plan64 *pl, int mode, int logT, const RowArgs64 &A, hipStream_t st, const ProfHook64 *prof) {
+  if (prof) prof->begin(prof->self, mode == 2 ? NTTX_K_ROW_MUL : mode == 0 ? NTTX_K_ROW_FWD : NTTX_K_ROW_INV, st);
+  const int rc = mode == 0 ? launch_row64_m<0>(pl, logT, A, st) : mode == 1 ? launch_row64_m<1>(pl, logT, A, st) : launch_row64_m<2>(pl, logT, A, st);
+  if (prof) prof->end(prof->self, st);
+  return rc;
+}
+
+template <bool INV, bool SAFE, bool PLO1, bool ZHI>
+static int launch_col64_t(int logT, const ColArgs64 &A, int nvec, hipStream_t st) {
+  const long long tiles = A.nblocks << (A.logS - 4);
+  const int grid = grid_for64(tiles, std::max(1, 2048 / nvec));
+#define NTTX_COL64_CASE(K) case K: \
+    hipLaunchKernelGGL((col64_kernel<K, INV, SAFE, PLO1, ZHI>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
+  switch (logT) {
+    NTTX_COL64_CASE(6) NTTX_COL64_CASE(7) NTTX_COL64_CASE(8) NTTX_COL64_CASE(9)
+    default: return fail64(NTTX_ERANGE, "column pass of 2^%d points unsupported", logT);
+  }
+#undef NTTX_COL64_CASE
+  HIPCHK64(hipGetLastError());
+  return 0;
+}
+template <bool INV, bool ZHI>
+static int launch_col64_c(const Plan64 *pl, int logT, const ColArgs64 &A, int nvec, hipStream_t st) {
+  if (pl->safe) return pl->plo1 ? launch_col64_t<INV, true, true, ZHI>(logT, A, nvec, st) : launch_col64_t<INV, true, false, ZHI>(logT, A, nvec, st);
+  return pl->plo1 ? launch_col64_t<INV, false, true, ZHI>(logT, A, nvec, st) : launch_col64_t<INV, false, false, ZHI>(logT, A, nvec, st);
+}
+static int launch_col64(const Plan64 *pl, bool inv, int logT, const ColArgs64 &A, int nvec, hipStream_t st, const ProfHook64 *prof) {
+  if (logT < kMinCol64 || logT > kMaxCol64 || A.logS < 4) return fail64(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
+  if (prof) prof->begin(prof->self, inv ? NTTX_K_COL_INV : NTTX_K_COL_FWD, st);
+  const int rc = inv ? launch_col64_c<true, false>(pl, logT, A, nvec, st)
+                     : (A.nvalid > 0 ? launch_col64_c<false, true>(pl, logT, A, nvec, st) : launch_col64_c<false, false>(pl, logT, A, nvec, st));
+  if (prof) prof->end(prof->self, st);
+  return rc;
+}
+
+int engine64_reserve(Engine64 *e, int logL, int batch) {
+  const size_t vec = ((size_t)batch << logL) * 8;
+  if (int rc = e->wa.ensure(vec)) return rc;
+  return e->wb.ensure(vec);
+}
+
+int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
+                             int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof) {
+  Plan64 *pl;
+  if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
+  const long long len = 1ll << logL;
+  if (pl->npass == 1) {
+    RowArgs64 R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
+    R.ctx = pl->ctx; R.pre = pl->pre_single; R.canon_out = 1; R.nrows = batch;
+    return launch_row64(pl, 2, pl->lt[0], R, st, prof);
+  }
+  if (int rc = engine64_reserve(e, logL, batch)) return rc;
+  uint64_t *wa = (uint64_t *)e->wa.ptr, *wb = (uint64_t *)e->wb.ptr;
+  const int ncol = pl->npass - 1;
+  int logN = logL;
+  for (int lv = 0; lv < ncol; ++lv) {
+    ColArgs64 C{}; C.in[0] = lv == 0 ? a : wa; C.in[1] = lv == 0 ? b : wb; C.out[0] = wa; C.out[1] = wb;
+    C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
+    C.nblocks = ((long long)batch << logL) >> logN;
+    C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
+    if (int rc = launch_col64(pl, false, pl->lt[lv], C, 2, st, prof)) return rc;
+    logN = C.logS;
+  }
+  {
+    RowArgs64 R{}; R.in0 = wa; R.in1 = wb; R.out = c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
+    R.ctx = pl->ctx; R.pre = pl->ctx.r2; R.canon_out = 0; R.nrows = ((long long)batch << logL) >> pl->lt[ncol];
+    if (int rc = launch_row64(pl, 2, pl->lt[ncol], R, st, prof)) return rc;
+  }
+  for (int lv = ncol - 1; lv >= 0; --lv) {
+    int logNl = logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
+    ColArgs64 C{}; C.in[0] = c; C.out[0] = c; C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx;
+    C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0); C.nblocks = ((long long)batch << logL) >> logNl;
+    if (int rc = launch_col64(pl, true, pl->lt[lv], C, 1, st, prof)) return rc;
+  }
+  return 0;
+}
+
+int engine64_forward(Engine64 *e, uint64_t *x, int logL, uint64_t p, int inverse, int batch, hipStream_t st,
+                     const ProfHook64 *prof) {
+  Plan64 *pl;
+  if (int rc = get_plan64(e, p, logL, inverse != 0, &pl)) return rc;
+  int logN = logL;
+  const int ncol = pl->npass - 1;
+  for (int lv = 0; lv < ncol; ++lv) {
+    ColArgs64 C{}; C.in[0] = x; C.out[0] = x; C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx;
+    C.logS = logN - pl->lt[lv]; C.canon_out = 0; C.nblocks = ((long long)batch << logL) >> logN;
+    if (int rc = launch_col64(pl, false, pl->lt[lv], C, 1, st, prof)) return rc;
+    logN = C.logS;
+  }
+  RowArgs64 R{}; R.in0 = x; R.out = x; R.tw_fwd = pl->tw_fwd[ncol]; R.ctx = pl->ctx; R.canon_out = 1;
+  R.nrows = ((long long)batch << logL) >> pl->lt[ncol];
+  return launch_row64(pl, 0, pl->lt[ncol], R, st, prof);
+}
+
+static dim3 ew_grid64(long long per_vec, int batch, int z) {
+  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
+}
+
+int engine64_pad(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *pa, uint64_t *pb, int n, int logL,
+                 uint64_t p, int batch, hipStream_t st) {
+  Plan64 *pl;
+  if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
+  PadArgs64 P{}; P.src[0] = a; P.src[1] = b; P.dst[0] = pa; P.dst[1] = pb; P.ctx = pl->ctx; P.n = n; P.len = 1 << logL;
+  P.zfill = pl->npass == 1 ? P.len : n;
+  if (pl->plo1) hipLaunchKernelGGL((pad64_kernel<true>), ew_grid64(P.zfill, batch, 2), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL((pad64_kernel<false>), ew_grid64(P.zfill, batch, 2), dim3(256), 0, st, P);
+  HIPCHK64(hipGetLastError());
+  return 0;
+}
+
+int engine64_unpad(const uint64_t *src, uint64_t *dst, int nout, int logL, int batch, hipStream_t st) {
+  hipLaunchKernelGGL(unpad64_kernel, ew_grid64(nout, batch, 1), dim3(256), 0, st, src, dst, nout, 1 << logL);
+  HIPCHK64(hipGetLastError());
+  return 0;
+}
+
+}  // namespace nttx

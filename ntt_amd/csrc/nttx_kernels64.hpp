@@ -1,0 +1,433 @@
+// gfx950 kernels of the 64-bit-lane direct path: one transform modulo p itself for
+// NTT-friendly moduli beyond 32 bits (2^31 <= p < 2^62, 2^k | p-1), instead of four
+// 32-bit transforms plus CRT recombination (main.cc:286-338 always takes the latter; the
+// single-prime structure is get_result of monttry2.cpp:319-343 on wider lanes).
+//
+// Same pass structure as the 32-bit kernels (column passes with a four-step multiply,
+// contiguous row passes, forward decimation-in-frequency / inverse decimation-in-time so no
+// permutation is run), radix-8 units on registers exchanged through LDS.  Residues are u64 in
+// ordinary form, constants in Montgomery form with R = 2^64.
+//
+// Reduction comes in two classes chosen per modulus:
+//   LAZY (p < 2^51): no conditional subtraction anywhere.  Forward sums double their bound per
+//        stage (2^(s+1) p after s stages, at most 2^12 p < 2^63), inverse sums add 2p per stage,
+//        and every multiplication by a constant brings a value back below 2p whatever it held.
+//   SAFE (p < 2^62): every sum and difference is brought back below 2p (Harvey butterflies).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nttx_arith.hpp"
+
+namespace nttx {
+
+// x*w*2^-64 mod p in [0, 2p) for any 64-bit x and canonical w < p < 2^62.
+// PLO1: p = 1 mod 2^32 (true for every modulus whose p-1 is divisible by 2^32, such as
+// 19*2^46+1): word-serial REDC with radix 2^32, where -p^-1 mod 2^32 = -1 and p's low word
+// is 1, so each of the two reduction steps is one negation and one 32x32 multiply:
+// six v_mad_u64_u32 in all.  Otherwise the two-multiply-high form is used.
+template <bool PLO1>
+__device__ __forceinline__ uint64_t mont64_lazy(uint64_t x, uint64_t w, uint64_t p, uint64_t npinv) {
+  if constexpr (PLO1) {
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t ph = (uint32_t)(p >> 32);
+    const uint64_t u = (uint64_t)x0 * w0;
+    const uint32_t a0 = (uint32_t)u;
+    const uint64_t v = (uint64_t)x0 * w1 + (u >> 32);                         // words 1..2 of x0*w
+    const uint32_t m = 0u - a0;                                               // a0 + m = 2^32 * (a0 != 0)
+    const uint64_t v2 = (uint64_t)m * ph + ((uint64_t)(uint32_t)v + (a0 != 0 ? 1u : 0u));
+    const uint32_t b1 = (uint32_t)(v >> 32) + (uint32_t)(v2 >> 32);           // (x0*w + m*p) / 2^32 < 2^63
+    const uint32_t b0 = (uint32_t)v2;
+    const uint64_t u2 = (uint64_t)x1 * w0 + b0;
+    const uint32_t c0 = (uint32_t)u2;
+    const uint64_t v3 = (uint64_t)x1 * w1 + ((uint64_t)b1 + (u2 >> 32));
+    const uint32_t m2 = 0u - c0;
+    const uint64_t v4 = (uint64_t)m2 * ph + ((uint64_t)(uint32_t)v3 + (c0 != 0 ? 1u : 0u));
+    const uint32_t d1 = (uint32_t)(v3 >> 32) + (uint32_t)(v4 >> 32);
+    return ((uint64_t)d1 << 32) | (uint32_t)v4;
+  } else {
+    const uint64_t lo = x * w, hi = __umul64hi(x, w);
+    const uint64_t m = lo * npinv;
+    return hi + __umul64hi(m, p) + (lo != 0 ? 1u : 0u);
+  }
+}
+
+__device__ __forceinline__ uint64_t csub64(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
+
+struct PrimeArgs64 {
+  uint64_t p, npinv;
+  uint64_t one;    // R mod p: multiplying by it reduces a value without changing it
+  uint64_t r2;     // R^2 mod p
+};
+
+template <bool SAFE, bool PLO1>
+struct Arith64 {
+  uint64_t p, npinv, p2;
+  __device__ __forceinline__ Arith64(const PrimeArgs64 &c) : p(c.p), npinv(c.npinv), p2(2 * c.p) {}
+  __device__ __forceinline__ uint64_t mul(uint64_t x, uint64_t w) const { return mont64_lazy<PLO1>(x, w, p, npinv); }
+  // bound (in multiples of p, as a shift) of forward values before stage s of a pass: 2^(s+1)
+  // bound of inverse values before stage s: 2, 4, 8, 16, then +2 per stage (twiddle-1 stages double)
+  __device__ __forceinline__ static constexpr int inv_bound(int s) { return s <= 3 ? (2 << s) : 16 + 2 * (s - 3); }
+  // Gentleman-Sande: (a, b) -> (a + b, (a - b) w); unit_w: w = 1; zhi: b is known to be zero
+  __device__ __forceinline__ void dif(uint64_t &a, uint64_t &b, uint64_t w, bool unit_w, bool zhi, int s) const {
+    if (zhi) { b = unit_w ? a : mul(a, w); return; }
+    if constexpr (SAFE) {
+      const uint64_t sum = csub64(a + b, p2), d = a - b + p2;
+      b = unit_w ? csub64(d, p2) : mul(d, w);
+      a = sum;
+    } else {
+      const uint64_t sum = a + b, d = a - b + (p << (s + 1));
+      b = unit_w ? d : mul(d, w);
+      a = sum;
+    }
+  }
+  // Cooley-Tukey: (a, b) -> (a + b w, a - b w)
+  __device__ __forceinline__ void dit(uint64_t &a, uint64_t &b, uint64_t w, bool unit_w, int s) const {
+    const uint64_t t = unit_w ? b : mul(b, w);
+    if constexpr (SAFE) {
+      b = csub64(a - t + p2, p2);
+      a = csub64(a + t, p2);
+    } else {
+      const uint64_t off = unit_w ? p * (uint64_t)inv_bound(s) : p2;
+      b = a - t + off;
+      a = a + t;
+    }
+  }
+  // fully reduced value of x (any history in the LAZY class, below 2p in the SAFE class)
+  __device__ __forceinline__ uint64_t canon(uint64_t x, uint64_t one) const {
+    if constexpr (SAFE) return csub64(x, p);
+    else return csub64(mul(x, one), p);
+  }
+};
+
+// radix-2^R unit on registers, stages at point distances 2^(R-1) D ... D (forward) or D ... (inverse);
+// w[m] = tw[lo + m*D]; D1: D == 1, where the twiddles of local index 0 equal 1; sbase = index of
+// the unit's first stage inside its pass (for the LAZY bounds)
+template <int R, bool INV, bool D1, bool ZHI, class AR>
+__device__ __forceinline__ void unit64(uint64_t (&x)[1 << R], const uint64_t (&w)[1 << R], const AR &M, int sbase) {
+  constexpr int NP = 1 << R;
+  if constexpr (!INV) {
+#pragma unroll
+    for (int st = 0; st < R; ++st) {
+      const int half = NP >> (st + 1);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i & half) continue;
+        const int j = i & (half - 1);
+        M.dif(x[i], x[i + half], w[half + j], D1 && j == 0, ZHI && st == 0, sbase + st);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int st = 0; st < R; ++st) {
+      const int half = 1 << st;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i & half) continue;
+        const int j = i & (half - 1);
+        M.dit(x[i], x[i + half], w[half + j], D1 && j == 0, sbase + st);
+      }
+    }
+  }
+}
+
+// LDS layouts in 64-bit words (the padding keeps per-point offsets compile-time constants, as in
+// the 32-bit layouts): rows get 4 pad words after every 32, column tiles one pad row after every 8.
+template <int LOGT_>
+struct RowLayout64 {
+  static constexpr int LOGT = LOGT_;
+  static constexpr int T = 1 << LOGT;
+  static constexpr int TP = T + (T >> 5) * 4;
+  static constexpr int NT = (T >= 2048) ? 1 : (2048 >> LOGT);
+  static constexpr int WORDS = NT * TP;
+  static constexpr int NTHR = 256;
+  __device__ static constexpr int padj(int j) { return j + ((j >> 5) << 2); }
+  __device__ static __forceinline__ int addr(int c, int j) { return c * TP + padj(j); }
+  template <int LOGU>
+  __device__ static __forceinline__ void split(int g, int &c, int &u) { c = g >> LOGU; u = g & ((1 << LOGU) - 1); }
+};
+
+template <int LOGT_, int LOGC_, int NTHR_>
+struct ColLayout64 {
+  static constexpr int LOGT = LOGT_, LOGC = LOGC_;
+  static constexpr int T = 1 << LOGT;
+  static constexpr int COLS = 1 << LOGC;
+  static constexpr int NT = COLS;
+  static constexpr int NTHR = NTHR_;
+  static constexpr int ROWS = T + (T >> 3);
+  static constexpr int WORDS = ROWS * COLS;
+  __device__ static constexpr int padj(int j) { return (j + (j >> 3)) * COLS; }
+  __device__ static __forceinline__ int addr(int c, int j) { return padj(j) + c; }
+  template <int LOGU>
+  __device__ static __forceinline__ void split(int g, int &c, int &u) { c = g & (COLS - 1); u = g >> LOGC; }
+};
+
+// one round: every radix-2^R unit at distance 2^LOGD of every transform of the tile, NV vectors
+template <class L, int R, int LOGD, bool INV, class AR, int NV, bool ZHI>
+__device__ __forceinline__ void ntt_round64(uint64_t *const (&s)[NV], const uint64_t *tw, const AR &M) {
+  constexpr int D = 1 << LOGD;
+  constexpr int LOG_UNITS = L::LOGT - R;
+  constexpr int TOTAL = L::NT << LOG_UNITS;
+  constexpr int NP = 1 << R;
+  constexpr int SBASE = INV ? LOGD : L::LOGT - (LOGD + R);
+  for (int g = threadIdx.x; g < TOTAL; g += L::NTHR) {
+    int c, u;
+    L::template split<LOG_UNITS>(g, c, u);
+    const int lo = u & (D - 1), hi = u >> LOGD;
+    const int base = (hi << (LOGD + R)) + lo;
+    const int a0 = L::addr(c, base);
+    uint64_t w[NP];
+    w[0] = 0;
+#pragma unroll
+    for (int m = 1; m < NP; ++m) w[m] = tw[lo + m * D];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      uint64_t x[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) x[q] = (ZHI && q >= NP / 2) ? 0ull : s[v][a0 + L::padj(q * D)];
+      unit64<R, INV, D == 1, ZHI, AR>(x, w, M, SBASE);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) s[v][a0 + L::padj(q * D)] = x[q];
+    }
+  }
+}
+
+template <class L, int REM, class AR, int NV, bool ZTOP>
+__device__ __forceinline__ void dif_rounds64(uint64_t *const (&s)[NV], const uint64_t *tw, const AR &M) {
+  constexpr bool zt = ZTOP && REM == L::LOGT;
+  if constexpr (REM > 3) {
+    ntt_round64<L, 3, REM - 3, false, AR, NV, zt>(s, tw, M);
+    __syncthreads();
+    dif_rounds64<L, REM - 3, AR, NV, ZTOP>(s, tw, M);
+  } else {
+    ntt_round64<L, REM, 0, false, AR, NV, zt>(s, tw, M);
+  }
+}
+
+template <class L, int REM, class AR, int NV>
+__device__ __forceinline__ void dit_rounds64(uint64_t *const (&s)[NV], const uint64_t *tw, const AR &M) {
+  if constexpr (REM > 3) {
+    dit_rounds64<L, REM - 3, AR, NV>(s, tw, M);
+    __syncthreads();
+    ntt_round64<L, 3, REM - 3, true, AR, NV, false>(s, tw, M);
+  } else {
+    ntt_round64<L, REM, 0, true, AR, NV, false>(s, tw, M);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Row kernel: transforms are contiguous runs of T words.
+//   MODE 0: forward (natural in, bit-reversed out), 1: inverse, 2: forward a, forward b,
+//   pointwise product, inverse.
+// ------------------------------------------------------------------------------------
+struct RowArgs64 {
+  const uint64_t *in0, *in1;
+  uint64_t *out;
+  const uint64_t *tw_fwd, *tw_inv;   // stage-major tables, T words
+  PrimeArgs64 ctx;
+  uint64_t pre;          // MODE 2: Montgomery constant applied to a before a*b: R^2 (times n^-1 on single-pass lengths)
+  int canon_out;
+  long long nrows;
+};
+
+template <class L>
+__device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long long row0, long long nrows) {
+  constexpr int T = L::T;
+  if constexpr (T >= 2) {
+    constexpr int NV2 = L::NT * T / 2;
+    for (int v = threadIdx.x; v < NV2; v += L::NTHR) {
+      const int c = (v * 2) >> L::LOGT, j = (v * 2) & (T - 1);
+      ulonglong2 x = make_ulonglong2(0, 0);
+      if (row0 + c < nrows) x = *reinterpret_cast<const ulonglong2 *>(in + (row0 + c) * T + j);
+      *reinterpret_cast<ulonglong2 *>(s + L::addr(c, j)) = x;
+    }
+  }
+}
+
+template <int LOGT, int MODE, bool SAFE, bool PLO1>
+__global__ void __launch_bounds__(256) row64_kernel(RowArgs64 A) {
+  using L = RowLayout64<LOGT>;
+  using AR = Arith64<SAFE, PLO1>;
+  constexpr int T = L::T;
+  constexpr int NVEC = (MODE == 2) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[NVEC * L::WORDS + (MODE == 2 ? 2 : 1) * T];
+  uint64_t *sa = lds, *sb = lds + (NVEC - 1) * L::WORDS;
+  uint64_t *twf = lds + NVEC * L::WORDS;
+  uint64_t *twi = twf + (MODE == 2 ? T : 0);
+  const AR M(A.ctx);
+  if (MODE != 1) for (int i = threadIdx.x; i < T; i += L::NTHR) twf[i] = A.tw_fwd[i];
+  if (MODE != 0) for (int i = threadIdx.x; i < T; i += L::NTHR) twi[i] = A.tw_inv[i];
+
+  for (long long row0 = (long long)blockIdx.x * L::NT; row0 < A.nrows; row0 += (long long)gridDim.x * L::NT) {
+    __syncthreads();
+    row_load64<L>(sa, A.in0, row0, A.nrows);
+    if (MODE == 2) row_load64<L>(sb, A.in1, row0, A.nrows);
+    __syncthreads();
+    if (MODE == 0) {
+      uint64_t *const v[1] = {sa};
+      dif_rounds64<L, LOGT, AR, 1, false>(v, twf, M);
+    } else if (MODE == 1) {
+      uint64_t *const v[1] = {sa};
+      dit_rounds64<L, LOGT, AR, 1>(v, twi, M);
+    } else {
+      uint64_t *const v2[2] = {sa, sb};
+      dif_rounds64<L, LOGT, AR, 2, false>(v2, twf, M);
+      __syncthreads();
+      // pointwise: (a * pre) is below 2p whatever a held, so its product with b (< 2^12 p) fits REDC
+      for (int i = threadIdx.x; i < L::NT * T; i += L::NTHR) {
+        const int ad = L::addr(i >> LOGT, i & (T - 1));
+        sa[ad] = M.mul(M.mul(sa[ad], A.pre), sb[ad]);
+      }
+      __syncthreads();
+      uint64_t *const v[1] = {sa};
+      dit_rounds64<L, LOGT, AR, 1>(v, twi, M);
+    }
+    __syncthreads();
+    constexpr int NV2 = L::NT * T / 2;
+    for (int v = threadIdx.x; v < NV2; v += L::NTHR) {
+      const int c = (v * 2) >> LOGT, j = (v * 2) & (T - 1);
+      if (row0 + c < A.nrows) {
+        ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(sa + L::addr(c, j));
+        if (A.canon_out) { x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one); }
+        *reinterpret_cast<ulonglong2 *>(A.out + (row0 + c) * T + j) = x;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Column kernel: T points at stride S inside blocks of N = T*S words; tile = T rows x 16
+// contiguous columns (128-byte row segments).  Forward multiplies point (j', s) by
+// fs[j'*S + s] = w_N^(s * bitrev_T(j')) on the way out, inverse by the inverse table on the way in.
+// ZHI (forward): rows from T/2 on hold the zero padding of a linear product and are not read;
+// nvalid = words of each block that hold data.
+// ------------------------------------------------------------------------------------
+struct ColArgs64 {
+  const uint64_t *in[2];
+  uint64_t *out[2];
+  const uint64_t *tw, *fs;
+  PrimeArgs64 ctx;
+  int logS;
+  int canon_out;
+  long long nblocks;
+  long long nvalid;
+};
+
+template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI>
+__global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
+  constexpr int LOGC = 4, NTHR = 512;
+  using L = ColLayout64<LOGT, LOGC, NTHR>;
+  using AR = Arith64<SAFE, PLO1>;
+  constexpr int T = L::T, COLS = L::COLS;
+  constexpr int LPR = COLS / 2, LOG_LPR = LOGC - 1;     // lanes per row segment, 16 bytes each
+  constexpr int PER = (T * LPR) / NTHR;
+  constexpr int RSTEP = NTHR / LPR;
+  constexpr int PERL = ZHI ? (PER + 1) / 2 : PER;
+  static_assert(PER >= 1 && PER * NTHR == T * LPR, "tile must be a whole number of pieces per thread");
+  static_assert(!ZHI || (!INV && (PER % 2 == 0 || PER == 1)), "zero-half variant is forward only");
+  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + T];
+  uint64_t *s = lds, *tw = lds + L::WORDS;
+  const AR M(A.ctx);
+  const uint64_t *in = A.in[blockIdx.z];
+  uint64_t *out = A.out[blockIdx.z];
+  const int logS = A.logS;
+  const int log_tpb = logS - LOGC;
+  const long long ntiles = A.nblocks << log_tpb;
+  const int j0 = threadIdx.x >> LOG_LPR, c2 = (threadIdx.x & (LPR - 1)) * 2;
+
+  for (int i = threadIdx.x; i < T; i += NTHR) tw[i] = A.tw[i];
+
+  auto tile_base = [&](long long t) -> long long {
+    const long long blk = t >> log_tpb;
+    const long long ct = t & ((1ll << log_tpb) - 1);
+    return (blk << (logS + LOGT)) + (ct << LOGC);
+  };
+  auto fs_base = [&](long long t) -> long long { return (t & ((1ll << log_tpb) - 1)) << LOGC; };
+  auto load_piece = [&](long long base, long long t_, int j) -> ulonglong2 {
+    if constexpr (!ZHI) {
+      return *reinterpret_cast<const ulonglong2 *>(in + base + ((long long)j << logS) + c2);
+    } else {
+      const long long ct = t_ & ((1ll << log_tpb) - 1);
+      const long long w0 = ((long long)j << logS) + (ct << LOGC) + c2;
+      ulonglong2 x = make_ulonglong2(0, 0);
+      if (j < T / 2 && w0 < A.nvalid) {
+        x = *reinterpret_cast<const ulonglong2 *>(in + base + ((long long)j << logS) + c2);
+        if (w0 + 1 >= A.nvalid) x.y = 0;
+      }
+      return x;
+    }
+  };
+  ulonglong2 nx[PERL];
+  long long t0 = blockIdx.x;
+  if (t0 < ntiles) {
+    const long long base = tile_base(t0);
+#pragma unroll
+    for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, t0, j0 + k * RSTEP);
+  }
+  for (; t0 < ntiles; t0 += gridDim.x) {
+    const long long gbase = tile_base(t0), fbase = fs_base(t0);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PERL; ++k) {
+      ulonglong2 x = nx[k];
+      const int j = j0 + k * RSTEP;
+      if (INV) {
+        const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
+        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
+      }
+      *reinterpret_cast<ulonglong2 *>(s + L::addr(c2, j)) = x;
+    }
+    if (t0 + gridDim.x < ntiles) {
+      const long long tn = t0 + gridDim.x, base = tile_base(tn);
+#pragma unroll
+      for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, tn, j0 + k * RSTEP);
+    }
+    __syncthreads();
+    uint64_t *const vec[1] = {s};
+    if constexpr (!INV) dif_rounds64<L, LOGT, AR, 1, ZHI>(vec, tw, M);
+    else dit_rounds64<L, LOGT, AR, 1>(vec, tw, M);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int j = j0 + k * RSTEP;
+      ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(s + L::addr(c2, j));
+      if (!INV) {
+        const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
+        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
+        if (A.canon_out) { x.x = csub64(x.x, M.p); x.y = csub64(x.y, M.p); }
+      } else if (A.canon_out) {
+        x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one);
+      }
+      *reinterpret_cast<ulonglong2 *>(out + gbase + ((long long)j << logS) + c2) = x;
+    }
+  }
+}
+
+// compact [batch][n] -> zero-padded [batch][len] (words n..zfill-1 zeroed), values >= p reduced
+struct PadArgs64 {
+  const uint64_t *src[2];
+  uint64_t *dst[2];
+  PrimeArgs64 ctx;
+  int n, len, zfill;
+};
+template <bool PLO1>
+__global__ void pad64_kernel(PadArgs64 A) {
+  const long long b = blockIdx.y;
+  const uint64_t *src = A.src[blockIdx.z] + b * A.n;
+  uint64_t *dst = A.dst[blockIdx.z] + b * A.len;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
+    uint64_t x = (j < A.n) ? src[j] : 0ull;
+    if (x >= A.ctx.p) {   // x -> x R -> x, each step a REDC that leaves a value below 2p
+      const uint64_t xr = mont64_lazy<PLO1>(x, A.ctx.r2, A.ctx.p, A.ctx.npinv);
+      x = csub64(mont64_lazy<PLO1>(xr, 1ull, A.ctx.p, A.ctx.npinv), A.ctx.p);
+    }
+    dst[j] = x;
+  }
+}
+
+__global__ void unpad64_kernel(const uint64_t *src, uint64_t *dst, int nout, int len) {
+  const long long b = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
+    dst[b * nout + j] = src[b * len + j];
+}
+
+}  // namespace nttx

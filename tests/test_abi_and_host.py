@@ -55,7 +55,12 @@ def test_path_selection():
     assert ntt_amd.path_for(104857601, 131072) == D
     assert ntt_amd.path_for(469762049, 131072) == D
     assert ntt_amd.path_for(1224736769, 131072) == D        # > 2^30: canonical-lane kernels
-    assert ntt_amd.path_for(1337006139375617, 131072) == C  # 51-bit modulus (test.o:11)
+    D64 = ntt_amd.PATH_DIRECT64
+    assert ntt_amd.path_for(1337006139375617, 131072) == D64  # 51-bit modulus (test.o:11) = 19*2^46+1
+    assert ntt_amd.path_for(1337006139375617, 1 << 28) == D64 # 2^29 transform, three passes
+    assert ntt_amd.path_for(1337006139375617, 1 << 29) == C   # beyond the longest 64-bit-lane plan
+    assert ntt_amd.path_for((1 << 61) - 1, 8) == C            # prime beyond 32 bits without the roots
+    assert ntt_amd.path_for(4611685941117976577, 1000) == D64 # just below 2^62
     assert ntt_amd.path_for(1000000007, 8) == C             # prime but 2^4 does not divide p-1
     assert ntt_amd.path_for(7340033 * 3, 4) == C            # composite
 

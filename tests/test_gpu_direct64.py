@@ -1,0 +1,153 @@
+"""GPU parity of the 64-bit-lane direct path (one transform modulo p itself for NTT-friendly
+moduli between 2^31 and 2^62) through the C ABI.  Checkers: the oracle's CRT product (the
+restatement of main.cc, exact while n*(p-1)^2 stays below the product of its four primes), its
+schoolbook product for the moduli beyond that bound, the forced CRT route of the library on
+the same inputs, and evaluation of both sides at random points for full-size cases."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P_ID4 = 1337006139375617          # 19 * 2^46 + 1: harness id 4 (lazy class, low word 1)
+PRIMES = {
+    "lazy_lo1": P_ID4,
+    "lazy_lo1_b": 263882790666241,          # 15 * 2^44 + 1
+    "lazy_lo1_top": 2251756864012289,       # just below 2^51
+    "lazy": 1125899437080577,               # 67108836 * 2^24 + 1
+    "lazy_small": 8588886017,               # 8191 * 2^20 + 1, just above 2^31
+    "safe_lo1": 4611685941117976577,        # just below 2^62, 2^32 | p-1
+    "safe": 2305843009146585089,            # 2^26 | p-1
+}
+
+
+def rand(oracle, n, seed, p):
+    return oracle.fill_random(n, seed, p).astype(np.uint64)
+
+
+def horner(coeffs, x, p):
+    acc = 0
+    for c in coeffs[::-1]:
+        acc = (acc * x + int(c)) % p
+    return acc
+
+
+@pytest.mark.parametrize("name", sorted(PRIMES))
+def test_paths_and_small_products(nttx, oracle, name):
+    p = PRIMES[name]
+    assert nttx.path_for(p, 1000) == nttx.PATH_DIRECT64
+    for n in (1, 2, 3, 5, 8, 31, 33, 64, 257, 1000, 1024, 1025, 2048):
+        a, b = rand(oracle, n, 7 * n + 1, p), rand(oracle, n, 7 * n + 2, p)
+        want = oracle.poly_multiply_naive_u64(a, b, p)
+        got = nttx.poly_multiply_direct64(a, b, n, p)
+        assert np.array_equal(got, want), (name, n)
+        assert np.array_equal(nttx.poly_multiply(a, b, n, p, dtype=np.uint64), want)
+
+
+@pytest.mark.parametrize("name,n", [("lazy_lo1", 4097), ("lazy", 20000), ("lazy_lo1_b", 65536), ("lazy_small", 70001),
+                                    ("lazy_lo1_top", 3000)])
+def test_two_pass_lengths_vs_crt_oracle(nttx, oracle, name, n):
+    p = PRIMES[name]
+    a, b = rand(oracle, n, 11, p), rand(oracle, n, 12, p)
+    want = oracle.poly_multiply_crt(a, b, p)
+    assert np.array_equal(nttx.poly_multiply_direct64(a, b, n, p), want)
+
+
+@pytest.mark.parametrize("name,n", [("safe_lo1", 5000), ("safe", 4100)])
+def test_two_pass_lengths_safe_class(nttx, oracle, name, n):
+    """Moduli beyond the CRT bound: schoolbook oracle."""
+    p = PRIMES[name]
+    a, b = rand(oracle, n, 21, p), rand(oracle, n, 22, p)
+    assert np.array_equal(nttx.poly_multiply_direct64(a, b, n, p), oracle.poly_multiply_naive_u64(a, b, p))
+
+
+def test_id4_full_size(nttx, oracle):
+    """n = 131072 on the modulus of harness id 4: equal to the oracle, to the library's CRT route and
+    to the sha256 of the compiled reference's own output for these inputs."""
+    p, n = P_ID4, 131072
+    a, b = rand(oracle, n, 1004, p), rand(oracle, n, 2004, p)
+    got = nttx.poly_multiply_direct64(a, b, n, p)
+    assert np.array_equal(got, oracle.poly_multiply_crt(a, b, p))
+    assert np.array_equal(got, nttx.poly_multiply_crt(a, b, n, p))
+    c = json.load(open(os.path.join(GOLD, "harness.json")))["cases"]["4_17"]
+    assert hashlib.sha256(got.astype("<u8").tobytes()).hexdigest() == c["sha256"]
+
+
+@pytest.mark.parametrize("name", ("safe_lo1", "safe", "lazy"))
+def test_full_size_by_evaluation(nttx, oracle, name):
+    """n = 131072 where no exact CPU product is cheap: a(x) b(x) = ab(x) at random points mod p."""
+    p, n = PRIMES[name], 131072
+    a, b = rand(oracle, n, 31, p), rand(oracle, n, 32, p)
+    got = nttx.poly_multiply_direct64(a, b, n, p)
+    assert got.max() < p
+    for x in (2, 0x123456789ABCDEF % p, p - 5):
+        assert horner(a, x, p) * horner(b, x, p) % p == horner(got, x, p)
+
+
+def test_inputs_not_reduced(nttx, oracle):
+    p, n = P_ID4, 700
+    a, b = rand(oracle, n, 41, p), rand(oracle, n, 42, p)
+    big_a = a + np.uint64(p) * np.uint64(5000)          # still below 2^64
+    big_b = b.copy()
+    big_b[::3] += np.uint64(p)
+    assert np.array_equal(nttx.poly_multiply_direct64(big_a, big_b, n, p), oracle.poly_multiply_crt(a, b, p))
+
+
+def test_three_pass_length(nttx, oracle):
+    """Product length 2^21 (three passes on 64-bit lanes) against the library's CRT route, the
+    longest length that route supports, on a 40-bit modulus (n p^2 must stay below the CRT bound);
+    the id 4 modulus at the same length by evaluation."""
+    p, n = 1099469684737, 1 << 20              # 262134 * 2^22 + 1
+    assert nttx.path_for(p, n) == nttx.PATH_DIRECT64
+    a, b = rand(oracle, n, 51, p), rand(oracle, n, 52, p)
+    got = nttx.poly_multiply_direct64(a, b, n, p)
+    assert np.array_equal(got, nttx.poly_multiply_crt(a, b, n, p))
+    p = P_ID4
+    a, b = rand(oracle, n, 53, p), rand(oracle, n, 54, p)
+    got = nttx.poly_multiply_direct64(a, b, n, p)
+    assert got.max() < p
+    for x in (3, p - 2):
+        assert horner(a, x, p) * horner(b, x, p) % p == horner(got, x, p)
+
+
+def test_device_resident_batch_and_transform(nttx, oracle):
+    p, n, batch = P_ID4, 3000, 5
+    L = 8192
+    a = np.zeros((batch, L), dtype=np.uint64)
+    b = np.zeros((batch, L), dtype=np.uint64)
+    for i in range(batch):
+        a[i, :n], b[i, :n] = rand(oracle, n, 60 + i, p), rand(oracle, n, 70 + i, p)
+    da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    dc = torch.empty_like(da)
+    nttx.reserve_u64(L, batch)
+    nttx.dev_direct_multiply_u64(da.data_ptr(), db.data_ptr(), dc.data_ptr(), n, p, batch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c = dc.cpu().numpy().view(np.uint64)
+    for i in range(batch):
+        assert np.array_equal(c[i, : 2 * n - 1], oracle.poly_multiply_crt(a[i, :n], b[i, :n], p))
+        assert not c[i, 2 * n - 1:].any()
+    assert torch.equal(da.cpu(), torch.from_numpy(a.view(np.int64)))       # inputs untouched
+    # transform level: X[bitrev(k)] = sum_j x[j] w^(jk), w = 3^((p-1)/len) (main.cc:156), on 64 points
+    T = 64
+    x = rand(oracle, T, 80, p)
+    dx = torch.from_numpy(x.view(np.int64).copy()).cuda()
+    nttx.dev_ntt_u64(dx.data_ptr(), T, p, False, 1, torch.cuda.current_stream().cuda_stream)
+    X = dx.cpu().numpy().view(np.uint64)
+    w = pow(3, (p - 1) // T, p)
+    for k in range(T):
+        want = sum(int(x[j]) * pow(w, j * k, p) for j in range(T)) % p
+        assert int(X[int(format(k, "06b")[::-1], 2)]) == want
+
+
+def test_errors(nttx):
+    a = np.ones(8, dtype=np.uint64)
+    with pytest.raises(nttx.NttxError):
+        nttx.poly_multiply_direct64(a, a, 8, 1337006139375617 + 2)      # not prime / no root
+    with pytest.raises(nttx.NttxError):
+        nttx.poly_multiply_direct64(a, a, 8, 469762049)                  # 32-bit modulus: other path
+    assert nttx.path_for((1 << 61) - 1, 8) == nttx.PATH_CRT4               # prime, but 2^4 does not divide p-1
