@@ -86,13 +86,7 @@ constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 
 static int decompose(int k, int lt[3]) {
   if (k <= kMaxRowLog) { lt[0] = k; return 1; }
-  if (k <= kMaxColLog + kMaxRowLog) {
-    lt[0] = k / 2;
-    static const int col_bias = [] { const char *e = getenv("NTTX_COL_BIAS"); return e ? atoi(e) : 0; }();   // experiments
-    if (lt[0] + col_bias >= kMinColLog && lt[0] + col_bias <= kMaxColLog && k - lt[0] - col_bias <= kMaxRowLog && k - lt[0] - col_bias >= 1) lt[0] += col_bias;
-    lt[1] = k - lt[0];
-    return 2;
-  }
+  if (k <= kMaxColLog + kMaxRowLog) { lt[0] = k / 2; lt[1] = k - lt[0]; return 2; }
   int row = (k + 2) / 3; if (row > kMaxRowLog) row = kMaxRowLog;
   int rem = k - row;
   lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
@@ -144,8 +138,6 @@ struct Context {
   DevBuf outb;              // compacted output staged for the copy back
   DevBuf tmp;               // transform API scratch
   Engine64 *e64 = nullptr;  // plans and workspace of the 64-bit-lane direct path
-  hipStream_t aux[2] = {nullptr, nullptr};   // side streams for pipelining launch groups
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
 static Context *g_ctx = nullptr;
 static std::mutex g_init_mu;
@@ -285,8 +277,7 @@ static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream
 // comfortably, 16 columns with 256 threads for the longest column passes.
 template <bool INV, int H, bool ZHI>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  static const int narrow = env_int("NTTX_COL16", 0);
-  const int wide = (logT <= 9 && A.logS >= 5 && !narrow) ? 1 : 0;
+  const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
   const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
   static const int capc = env_int("NTTX_GRID_COL", 2048);
   const int grid = (grid_for(tiles, std::max(1, capc / nvec)) + 15) / 16 * 16 <= tiles ? (grid_for(tiles, std::max(1, capc / nvec)) + 15) / 16 * 16 : grid_for(tiles, std::max(1, capc / nvec));
@@ -338,15 +329,6 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 
 // ---- device-resident building blocks ---------------------------------------------------
 
-// Multiplications per launch group of a multi-pass batch (default: the whole batch).
-static int chunk_for(int logL, int batch) {
-  static int forced = [] { const char *e = getenv("NTTX_CHUNK"); return e ? atoi(e) : 0; }();
-  if (forced > 0) return std::min(forced, batch);
-  (void)logL;
-  return batch;   // measured on MI355X: splitting a resident batch into cache-sized launches loses more
-                  // to short launches than residency wins; NTTX_CHUNK keeps the knob for experiments
-}
-
 // c = cyclic product of a and b, all [batch][2^logL] u32 on the device
 // nvalid > 0: only the first nvalid words of every input vector are read, the rest counts as zero
 // (the zero padding of a linear product, main.cc:280-281); needs nvalid <= len/2 to take effect.
@@ -358,56 +340,34 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     R.ctx = pl->ctx; R.scale = pl->scale_single; R.canon_out = 1; R.nrows = batch;
     return launch_row(cx, ROW_MUL, pl->hclass, pl->lt[0], R, st);
   }
-  // Launch groups.  With NTTX_SPLIT=G > 1 the batch is cut into G groups whose three-kernel chains are
-  // issued alternately on two side streams, so the memory-bound column passes of one group can overlap
-  // the VALU-bound row pass of the other.
-  static const int split = env_int("NTTX_SPLIT", 1);
-  const int groups = (split > 1 && batch >= 2 * split) ? split : 1;
-  const int chunk = groups > 1 ? (batch + groups - 1) / groups : chunk_for(pl->logL, batch);
-  const size_t wsz = (size_t)(groups > 1 ? batch : chunk) * len * 4;
+  // One launch per pass over the whole resident batch.  (Cutting the batch into cache-sized launch
+  // groups, or issuing groups on two streams so column and row passes overlap, both measured slower
+  // on MI355X: short launches lose more than residency or overlap wins.)
+  const size_t wsz = (size_t)batch * len * 4;
   if (int rc = cx->wa.ensure(wsz)) return rc;
   if (int rc = cx->wb.ensure(wsz)) return rc;
-  if (groups > 1) {
-    if (!cx->aux[0]) {
-      for (int i = 0; i < 2; ++i) { HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming)); }
-      HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
-    }
-    HIPCHK(hipEventRecord(cx->ev_fork, st));
-    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
-  }
+  uint32_t *wa = cx->wa.as<uint32_t>(), *wb = cx->wb.as<uint32_t>();
   const int ncol = pl->npass - 1;
-  int gi = 0;
-  for (int b0 = 0; b0 < batch; b0 += chunk, ++gi) {
-    const int nb = std::min(chunk, batch - b0);
-    hipStream_t gs = groups > 1 ? cx->aux[gi & 1] : st;
-    const size_t woff = groups > 1 ? (size_t)b0 * len : 0;
-    uint32_t *wa = cx->wa.as<uint32_t>() + woff, *wb = cx->wb.as<uint32_t>() + woff;
-    const uint32_t *ca = a + (size_t)b0 * len, *cb = b + (size_t)b0 * len;
-    uint32_t *cc = c + (size_t)b0 * len;
-    int logN = pl->logL;
-    for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
-      ColArgs C{}; C.in[0] = lv == 0 ? ca : wa; C.in[1] = lv == 0 ? cb : wb; C.out[0] = wa; C.out[1] = wb;
-      C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
-      C.nblocks = ((long long)nb << pl->logL) >> logN;
-      C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
-      if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, gs)) return rc;
-      logN = C.logS;
-    }
-    {                                              // rows: forward a, forward b, pointwise, inverse
-      RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = cc; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
-      R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)nb << pl->logL) >> pl->lt[ncol];
-      if (int rc = launch_row(cx, ROW_MUL, pl->hclass, pl->lt[ncol], R, gs)) return rc;
-    }
-    for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
-      int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
-      ColArgs C{}; C.in[0] = cc; C.in[1] = nullptr; C.out[0] = cc; C.out[1] = nullptr;
-      C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
-      C.nblocks = ((long long)nb << pl->logL) >> logNl;
-      if (int rc = launch_col(cx, true, pl->hclass, pl->lt[lv], C, 1, gs)) return rc;
-    }
+  int logN = pl->logL;
+  for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
+    ColArgs C{}; C.in[0] = lv == 0 ? a : wa; C.in[1] = lv == 0 ? b : wb; C.out[0] = wa; C.out[1] = wb;
+    C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
+    C.nblocks = ((long long)batch << pl->logL) >> logN;
+    C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
+    if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, st)) return rc;
+    logN = C.logS;
   }
-  if (groups > 1) {
-    for (int i = 0; i < 2; ++i) { HIPCHK(hipEventRecord(cx->ev_join[i], cx->aux[i])); HIPCHK(hipStreamWaitEvent(st, cx->ev_join[i], 0)); }
+  {                                              // rows: forward a, forward b, pointwise, inverse
+    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
+    R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
+    if (int rc = launch_row(cx, ROW_MUL, pl->hclass, pl->lt[ncol], R, st)) return rc;
+  }
+  for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
+    int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
+    ColArgs C{}; C.in[0] = c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
+    C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
+    C.nblocks = ((long long)batch << pl->logL) >> logNl;
+    if (int rc = launch_col(cx, true, pl->hclass, pl->lt[lv], C, 1, st)) return rc;
   }
   return 0;
 }
@@ -650,8 +610,6 @@ void nttx_shutdown(void) {
   g_ctx->slabs.clear();
   engine64_destroy(g_ctx->e64);
   g_ctx->prof.destroy();
-  for (int i = 0; i < 2; ++i) { if (g_ctx->aux[i]) (void)hipStreamDestroy(g_ctx->aux[i]); if (g_ctx->ev_join[i]) (void)hipEventDestroy(g_ctx->ev_join[i]); }
-  if (g_ctx->ev_fork) (void)hipEventDestroy(g_ctx->ev_fork);
   for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
     b->release();
   delete g_ctx;
@@ -699,10 +657,8 @@ int nttx_reserve(int len, int batch, int nprimes) {
   NTTX_ENTER();
   if (len < 2 || batch < 1 || nprimes < 1 || nprimes > 4) return fail(NTTX_EINVAL, "bad arguments");
   const size_t vec = (size_t)batch * len * 4;
-  int k = 0; while ((1ll << k) < len) ++k;
-  const size_t wvec = (size_t)chunk_for(k, batch) * len * 4;
-  if (int rc = cx->wa.ensure(wvec)) return rc;
-  if (int rc = cx->wb.ensure(wvec)) return rc;
+  if (int rc = cx->wa.ensure(vec)) return rc;
+  if (int rc = cx->wb.ensure(vec)) return rc;
   if (nprimes > 1) {
     if (int rc = cx->pa.ensure(nprimes * vec)) return rc;
     if (int rc = cx->pb.ensure(nprimes * vec)) return rc;
