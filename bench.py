@@ -79,14 +79,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # NTTX_BENCH_ONE_DEVICE=1 (rehearsal on a one-GPU box): every rank uses GPU 0 and the control-plane
+    # collectives (barrier, max of the elapsed time) run over gloo, since RCCL wants one GPU per rank
+    rehearsal = os.environ.get("NTTX_BENCH_ONE_DEVICE") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ntt_amd.init(local_rank)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    ntt_amd.init(device_index)
 
     L, n, B = 1 << LOG_L, 1 << (LOG_L - 1), args.batch
     # synthetic inputs, generated on the device: uniform in [0, p), upper half zero (padding)
@@ -140,7 +146,7 @@ def main():
     ntt_amd.profile_enable(False)
     prof = ntt_amd.profile_read()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
