@@ -408,11 +408,16 @@ static int fill_crt_args(CrtArgs &A, uint64_t p) {
   for (int k = 0; k < 4; ++k) { A.ctx[k] = cc.ctx[k]; for (int j = 0; j < 4; ++j) A.inv[k][j] = cc.inv[k][j]; }
   A.nmod = 4;
   if (p < 2 || p >= (1ull << 63)) return fail(NTTX_EINVAL, "modulus out of range");
-  if ((p & 1) == 0) return fail(NTTX_EINVAL, "even modulus %llu is not supported by the CRT recombination", (unsigned long long)p);
-  A.pctx = make_ctx64(p);
-  A.small_p = p <= (1ull << 31) ? 1 : 0;
-  const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % p);
-  for (int k = 0; k < 4; ++k) A.mR[k] = h_mulmod64(kCrtPrimes[k] % p, R, p);
+  int e = 0; uint64_t q = p;
+  while ((q & 1) == 0) { q >>= 1; ++e; }             // p = 2^e * q, q odd
+  A.e = e;
+  A.pctx = make_ctx64(q);                            // for q == 1 the odd part is skipped by the kernel
+  A.qinv = 0ull - A.pctx.npinv;                      // q^{-1} mod 2^64
+  A.small_p = q <= (1ull << 31) ? 1 : 0;
+  if (q > 1) {
+    const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % q);
+    for (int k = 0; k < 4; ++k) A.mR[k] = h_mulmod64(kCrtPrimes[k] % q, R, q);
+  }
   return 0;
 }
 

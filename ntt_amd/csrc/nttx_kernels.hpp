@@ -729,14 +729,18 @@ struct CrtArgs {
   uint64_t *out;            // [batch][nout]
   PrimeCtx ctx[4];
   uint32_t inv[4][4];       // inv[i][j] = m_i^{-1} mod m_j in Montgomery form (i < j)
-  PrimeCtx64 pctx;          // caller modulus
-  uint64_t mR[4];           // m_k * 2^64 mod p
+  // caller modulus p = 2^e * q, q odd: the value is evaluated modulo q on Montgomery lanes and modulo
+  // 2^e by wrapping 64-bit arithmetic, then joined (e = 0 for the odd moduli of the reference's inputs)
+  PrimeCtx64 pctx;          // q (unused when q == 1)
+  uint64_t mR[4];           // m_k * 2^64 mod q
+  uint64_t qinv;            // q^{-1} mod 2^64
+  int e;                    // p = 2^e * q
   int nmod, nout, len;
-  int small_p;              // p <= 2^31: digits must be reduced modulo p before they are added
+  int small_p;              // q <= 2^31: digits must be reduced modulo q before they are added
 };
 __global__ void crt_kernel(CrtArgs A) {
   const long long b = blockIdx.y;
-  const uint64_t p = A.pctx.p;
+  const uint64_t q = A.pctx.p;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.nout; j += gridDim.x * blockDim.x) {
     const long long src = b * A.len + j;
     uint32_t v[4];
@@ -746,18 +750,27 @@ __global__ void crt_kernel(CrtArgs A) {
         const uint32_t mk = A.ctx[k].p;
         uint32_t t = A.res[k][src];
 #pragma unroll
-        for (int q = 0; q < k; ++q) {
-          const uint32_t d = t - v[q];
-          t = mont_mul(t >= v[q] ? d : d + mk, A.inv[q][k], mk, A.ctx[k].npinv);
+        for (int i = 0; i < k; ++i) {
+          const uint32_t d = t - v[i];
+          t = mont_mul(t >= v[i] ? d : d + mk, A.inv[i][k], mk, A.ctx[k].npinv);
         }
         v[k] = t;
       }
     }
-    uint64_t r = A.small_p ? v[A.nmod - 1] % p : v[A.nmod - 1];
-    for (int k = A.nmod - 2; k >= 0; --k) {
-      r = mont_mul64(r, A.mR[k], p, A.pctx.npinv);
-      r += A.small_p ? v[k] % p : v[k];
-      if (r >= p) r -= p;
+    uint64_t r = 0;
+    if (q > 1) {
+      r = A.small_p ? v[A.nmod - 1] % q : v[A.nmod - 1];
+      for (int k = A.nmod - 2; k >= 0; --k) {
+        r = mont_mul64(r, A.mR[k], q, A.pctx.npinv);
+        r += A.small_p ? v[k] % q : v[k];
+        if (r >= q) r -= q;
+      }
+    }
+    if (A.e > 0) {   // even modulus: x mod 2^e from wrapping arithmetic, then x = r + q * ((x2 - r) / q mod 2^e)
+      uint64_t x2 = v[A.nmod - 1];
+      for (int k = A.nmod - 2; k >= 0; --k) x2 = x2 * A.ctx[k].p + v[k];
+      const uint64_t mask = A.e >= 64 ? ~0ull : ((1ull << A.e) - 1);
+      r += q * (((x2 - r) * A.qinv) & mask);
     }
     A.out[b * A.nout + j] = r;
   }

@@ -83,6 +83,25 @@ def test_crt_path_small(nttx, oracle, p):
             assert np.array_equal(want, oracle.poly_multiply_naive_u64(a, b, p))
 
 
+@pytest.mark.parametrize("p", (2, 3, 4, 6, 12, 17, 65536, 65537, 1 << 31, 3 << 40, 1 << 62, 1000000007, (1 << 61) - 1))
+def test_any_modulus_like_main_cc(nttx, oracle, p):
+    """main.cc reduces the exact integer product modulo whatever p it is given (main.cc:334-336):
+    small, even and composite moduli included, as long as n (p-1)^2 stays below its CRT bound."""
+    for n in (1, 4, 33, 500):
+        if n * (p - 1) ** 2 >= 469762049 * 998244353 * 1004535809 * 1224736769 and nttx.path_for(p, n) == nttx.PATH_CRT4:
+            with pytest.raises(nttx.NttxError):
+                nttx.poly_multiply(rand(oracle, n, 1, p), rand(oracle, n, 2, p), n, p, dtype=np.uint64)
+            continue
+        a, b = rand(oracle, n, 3 * n + 1, p), rand(oracle, n, 3 * n + 2, p)
+        want = oracle.poly_multiply_naive_u64(a, b, p)
+        if n * (p - 1) ** 2 < 469762049 * 998244353 * 1004535809 * 1224736769:
+            assert np.array_equal(oracle.poly_multiply_crt(a, b, p), want)
+        assert np.array_equal(nttx.poly_multiply(a, b, n, p, dtype=np.uint64), want), (p, n)
+        if p < (1 << 31):
+            got = nttx.poly_multiply(a.astype(np.int32), b.astype(np.int32), n, p, dtype=np.int32)
+            assert np.array_equal(got.astype(np.uint64), want), (p, n)
+
+
 @pytest.mark.parametrize("tid", (1, 2, 3, 4))
 def test_harness_sizes_full(nttx, oracle, tid):
     """n = 131072 (product length 2^18) on the four harness moduli, seeded inputs."""
