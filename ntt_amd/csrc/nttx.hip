@@ -322,6 +322,17 @@ static int launch_col(Context *cx, bool inv, int h, int logT, const ColArgs &A0,
   return rc;
 }
 
+static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+static void set_vec(SplitArgs &S) {
+  bool ok = (S.n & 3) == 0 && aligned16(S.src[0]) && aligned16(S.src[1]);
+  for (int k = 0; k < S.nmod; ++k) ok = ok && aligned16(S.dst[0][k]) && aligned16(S.dst[1][k]);
+  S.vec = ok ? 1 : 0;
+}
+static void set_vec(CrtArgs &A) {
+  bool ok = (A.len & 3) == 0;
+  for (int k = 0; k < A.nmod; ++k) ok = ok && aligned16(A.res[k]);
+  A.vec = ok ? 1 : 0;
+}
 static dim3 ew_grid2(long long per_vec, int batch, int z = 1) {
   return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
 }
@@ -413,10 +424,9 @@ static int fill_crt_args(CrtArgs &A, uint64_t p) {
   A.e = e;
   A.pctx = make_ctx64(q);                            // for q == 1 the odd part is skipped by the kernel
   A.qinv = 0ull - A.pctx.npinv;                      // q^{-1} mod 2^64
-  A.small_p = q <= (1ull << 31) ? 1 : 0;
   if (q > 1) {
-    const uint64_t R = (uint64_t)((((unsigned __int128)1) << 64) % q);
-    for (int k = 0; k < 4; ++k) A.mR[k] = h_mulmod64(kCrtPrimes[k] % q, R, q);
+    uint64_t c = (uint64_t)((((unsigned __int128)1) << 64) % q);     // 2^64 mod q
+    for (int k = 0; k < 4; ++k) { A.cR[k] = c; c = h_mulmod64(c, kCrtPrimes[k] % q, q); }
   }
   return 0;
 }
@@ -458,6 +468,7 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
       S.ctx[k] = pl[k]->ctx;
     }
     cx->prof.begin(PK_SPLIT, st);
+    set_vec(S);
     hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
     cx->prof.end(st);
     HIPCHK(hipGetLastError());
@@ -473,6 +484,7 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
   }
   A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len;
   cx->prof.begin(PK_CRT, st);
+  set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(A.nout, batch), dim3(256), 0, st, A);
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
@@ -503,6 +515,7 @@ static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_
     S.ctx[i] = pl[i]->ctx;
   }
   cx->prof.begin(PK_SPLIT, st);
+  set_vec(S);
   hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
@@ -519,6 +532,7 @@ static int dev_crt_recombine(Context *cx, const uint32_t *const r[4], uint64_t *
   for (int k = 0; k < 4; ++k) A.res[k] = r[k];
   A.out = d_out; A.nout = (int)count; A.len = (int)count;
   cx->prof.begin(PK_CRT, st);
+  set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(count, 1), dim3(256), 0, st, A);
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
@@ -787,6 +801,7 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
     A.res[k] = d;
   }
   A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len;
+  set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(nout, 1), dim3(256), 0, 0, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
@@ -932,6 +947,7 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
     SplitArgs S{}; S.src[0] = cx->in_a.as<uint64_t>(); S.src[1] = cx->in_b.as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len;
     S.zfill = pl->npass == 1 ? (int)len : n;
     S.dst[0][0] = cx->pa.as<uint32_t>(); S.dst[1][0] = cx->pb.as<uint32_t>(); S.ctx[0] = pl->ctx;
+    set_vec(S);
     hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, 1, 2), dim3(256), 0, 0, S);
   }
   HIPCHK(hipGetLastError());

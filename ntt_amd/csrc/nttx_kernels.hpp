@@ -675,21 +675,39 @@ struct SplitArgs {
   PrimeCtx ctx[4];
   int nmod;
   int n, len, zfill;
+  int vec;                  // n % 4 == 0 and all pointers 16-byte aligned
 };
+__device__ __forceinline__ uint32_t split_one(uint64_t x, const PrimeCtx &c) {
+  const uint32_t h = csub(mont_mul_lazy((uint32_t)(x >> 32), c.r2, c.p, c.npinv), c.p);   // hi * 2^32 mod m
+  const uint32_t l = csub(mont_mul_lazy((uint32_t)x, c.one, c.p, c.npinv), c.p);          // lo mod m
+  return csub(h + l, c.p);
+}
 __global__ void split_kernel(SplitArgs A) {
   const long long b = blockIdx.y;
   const uint64_t *src = A.src[blockIdx.z] + b * A.n;
+  if (A.vec) {   // rows are 16-byte aligned: four coefficients per thread, 16-byte accesses
+    for (int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4; j < A.zfill; j += gridDim.x * blockDim.x * 4) {
+      ulonglong2 x01 = make_ulonglong2(0, 0), x23 = make_ulonglong2(0, 0);
+      if (j < A.n) {
+        x01 = *reinterpret_cast<const ulonglong2 *>(src + j);
+        x23 = *reinterpret_cast<const ulonglong2 *>(src + j + 2);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < A.nmod) {
+          const PrimeCtx c = A.ctx[k];
+          const uint4 r = make_uint4(split_one(x01.x, c), split_one(x01.y, c), split_one(x23.x, c), split_one(x23.y, c));
+          *reinterpret_cast<uint4 *>(A.dst[blockIdx.z][k] + b * A.len + j) = r;
+        }
+      }
+    }
+    return;
+  }
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
     const uint64_t x = (j < A.n) ? src[j] : 0ull;
-    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (k < A.nmod) {
-        const PrimeCtx c = A.ctx[k];
-        const uint32_t h = csub(mont_mul_lazy(hi, c.r2, c.p, c.npinv), c.p);   // hi * 2^32 mod m
-        const uint32_t l = csub(mont_mul_lazy(lo, c.one, c.p, c.npinv), c.p);  // lo mod m
-        A.dst[blockIdx.z][k][b * A.len + j] = csub(h + l, c.p);
-      }
+      if (k < A.nmod) A.dst[blockIdx.z][k][b * A.len + j] = split_one(x, A.ctx[k]);
     }
   }
 }
@@ -732,47 +750,73 @@ struct CrtArgs {
   // caller modulus p = 2^e * q, q odd: the value is evaluated modulo q on Montgomery lanes and modulo
   // 2^e by wrapping 64-bit arithmetic, then joined (e = 0 for the odd moduli of the reference's inputs)
   PrimeCtx64 pctx;          // q (unused when q == 1)
-  uint64_t mR[4];           // m_k * 2^64 mod q
+  uint64_t cR[4];           // (m_0 ... m_{k-1}) * 2^64 mod q, canonical; cR[0] = 2^64 mod q
   uint64_t qinv;            // q^{-1} mod 2^64
   int e;                    // p = 2^e * q
   int nmod, nout, len;
-  int small_p;              // q <= 2^31: digits must be reduced modulo q before they are added
+  int vec;                  // len % 4 == 0 and every residue pointer 16-byte aligned: 16-byte loads
 };
+// x = v0 + m0 v1 + m0 m1 v2 + m0 m1 m2 v3 with 31-bit digits: S = sum v_k cR[k] < 2^33 q is reduced by
+// ONE 128-bit REDC (S / 2^64 < q / 2^31, so the result is at most q and one subtraction finishes).
+__device__ __forceinline__ uint64_t crt_one(const CrtArgs &A, const uint32_t (&res)[4]) {
+  const uint64_t q = A.pctx.p;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < A.nmod) {
+      const uint32_t mk = A.ctx[k].p;
+      uint32_t t = res[k];
+#pragma unroll
+      for (int i = 0; i < k; ++i) {
+        const uint32_t d = t - v[i];
+        t = mont_mul(t >= v[i] ? d : d + mk, A.inv[i][k], mk, A.ctx[k].npinv);
+      }
+      v[k] = t;
+    } else {
+      v[k] = 0;
+    }
+  }
+  uint64_t r = 0;
+  if (q > 1) {
+    unsigned __int128 S = (unsigned __int128)(uint64_t)v[0] * A.cR[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) S += (unsigned __int128)(uint64_t)v[k] * A.cR[k];
+    const uint64_t lo = (uint64_t)S, hi = (uint64_t)(S >> 64);
+    const uint64_t m = lo * A.pctx.npinv;
+    r = hi + mulhi64(m, q) + (lo != 0 ? 1u : 0u);
+    if (r >= q) r -= q;
+  }
+  if (A.e > 0) {   // even modulus: x mod 2^e from wrapping arithmetic, then x = r + q * ((x2 - r) / q mod 2^e)
+    uint64_t x2 = v[3];
+    for (int k = 2; k >= 0; --k) x2 = x2 * A.ctx[k].p + v[k];
+    const uint64_t mask = (1ull << A.e) - 1;
+    r += q * (((x2 - r) * A.qinv) & mask);
+  }
+  return r;
+}
+// four consecutive indices per thread (16-byte residue loads) when the rows allow it
 __global__ void crt_kernel(CrtArgs A) {
   const long long b = blockIdx.y;
-  const uint64_t q = A.pctx.p;
+  uint64_t *out = A.out + b * A.nout;
+  if (A.vec) {
+    for (int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4; j < A.nout; j += gridDim.x * blockDim.x * 4) {
+      uint4 x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = (k < A.nmod) ? *reinterpret_cast<const uint4 *>(A.res[k] + b * A.len + j) : make_uint4(0, 0, 0, 0);
+      const uint32_t r0[4] = {x[0].x, x[1].x, x[2].x, x[3].x}, r1[4] = {x[0].y, x[1].y, x[2].y, x[3].y};
+      const uint32_t r2[4] = {x[0].z, x[1].z, x[2].z, x[3].z}, r3[4] = {x[0].w, x[1].w, x[2].w, x[3].w};
+      out[j] = crt_one(A, r0);
+      if (j + 1 < A.nout) out[j + 1] = crt_one(A, r1);
+      if (j + 2 < A.nout) out[j + 2] = crt_one(A, r2);
+      if (j + 3 < A.nout) out[j + 3] = crt_one(A, r3);
+    }
+    return;
+  }
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.nout; j += gridDim.x * blockDim.x) {
-    const long long src = b * A.len + j;
-    uint32_t v[4];
+    uint32_t r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < A.nmod) {
-        const uint32_t mk = A.ctx[k].p;
-        uint32_t t = A.res[k][src];
-#pragma unroll
-        for (int i = 0; i < k; ++i) {
-          const uint32_t d = t - v[i];
-          t = mont_mul(t >= v[i] ? d : d + mk, A.inv[i][k], mk, A.ctx[k].npinv);
-        }
-        v[k] = t;
-      }
-    }
-    uint64_t r = 0;
-    if (q > 1) {
-      r = A.small_p ? v[A.nmod - 1] % q : v[A.nmod - 1];
-      for (int k = A.nmod - 2; k >= 0; --k) {
-        r = mont_mul64(r, A.mR[k], q, A.pctx.npinv);
-        r += A.small_p ? v[k] % q : v[k];
-        if (r >= q) r -= q;
-      }
-    }
-    if (A.e > 0) {   // even modulus: x mod 2^e from wrapping arithmetic, then x = r + q * ((x2 - r) / q mod 2^e)
-      uint64_t x2 = v[A.nmod - 1];
-      for (int k = A.nmod - 2; k >= 0; --k) x2 = x2 * A.ctx[k].p + v[k];
-      const uint64_t mask = A.e >= 64 ? ~0ull : ((1ull << A.e) - 1);
-      r += q * (((x2 - r) * A.qinv) & mask);
-    }
-    A.out[b * A.nout + j] = r;
+    for (int k = 0; k < 4; ++k) r[k] = (k < A.nmod) ? A.res[k][b * A.len + j] : 0u;
+    out[j] = crt_one(A, r);
   }
 }
 
