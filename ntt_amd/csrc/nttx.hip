@@ -244,7 +244,7 @@ template <int MODE, int H>
 static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
   if (MODE == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
     const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
-    static const int cap9 = env_int("NTTX_GRID_ROW", 256 * 8);
+    static const int cap9 = env_int("NTTX_GRID_ROW", 8192);   // 4 rows per wave at batch 256: measured optimum
     if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     else hipLaunchKernelGGL((row_mul9_kernel<H, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     HIPCHK(hipGetLastError());
@@ -279,8 +279,14 @@ template <bool INV, int H, bool ZHI>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
   const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
-  static const int capc = env_int("NTTX_GRID_COL", 2048);
-  const int grid = (grid_for(tiles, std::max(1, capc / nvec)) + 15) / 16 * 16 <= tiles ? (grid_for(tiles, std::max(1, capc / nvec)) + 15) / 16 * 16 : grid_for(tiles, std::max(1, capc / nvec));
+  // workgroups per launch (tuning knobs; any value is correct, workgroups stride over the tiles)
+  // Measured on MI355X: one tile per workgroup (the hardware dispatcher refills CUs as workgroups retire,
+  // which staggers their load / butterfly / store phases) beats a resident grid striding over the tiles
+  // by 12 % on the forward and 8 % on the inverse pass.
+  static const int capf = env_int("NTTX_GRID_COL", 1 << 20), capi = env_int("NTTX_GRID_COLI", 1 << 20);
+  const int cap = std::max(1, (INV ? capi : capf) / nvec);
+  const int g16 = (grid_for(tiles, cap) + 15) / 16 * 16;
+  const int grid = g16 <= tiles ? g16 : grid_for(tiles, cap);
 #define NTTX_COL_CASE(K, LC, NT) \
     hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
   switch (logT * 2 + wide) {
