@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -181,13 +182,15 @@ static int get_plan64(Engine64 *e, uint64_t p, int logL, bool conj, Plan64 **out
 
 // ---- launches ------------------------------------------------------------------------------
 static int grid_for64(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
+static int env_int64(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 template <int MODE, bool SAFE, bool PLO1>
 static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
 #define NTTX_ROW64_CASE(K) case K: { \
     using Lyt = RowLayout64<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, 4096)), dim3(256), 0, st, A); break; }
+    hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap_row)), dim3(256), 0, st, A); break; }
+  static const int cap_row = env_int64("NTTX_GRID_ROW64", 4096);
   switch (logT) {
     NTTX_ROW64_CASE(1) NTTX_ROW64_CASE(2) NTTX_ROW64_CASE(3) NTTX_ROW64_CASE(4) NTTX_ROW64_CASE(5) NTTX_ROW64_CASE(6)
     NTTX_ROW64_CASE(7) NTTX_ROW64_CASE(8) NTTX_ROW64_CASE(9) NTTX_ROW64_CASE(10) NTTX_ROW64_CASE(11)
@@ -212,7 +215,8 @@ static int launch_row64(const Plan64 *pl, int mode, int logT, const RowArgs64 &A
 template <bool INV, bool SAFE, bool PLO1, bool ZHI>
 static int launch_col64_t(int logT, const ColArgs64 &A, int nvec, hipStream_t st) {
   const long long tiles = A.nblocks << (A.logS - 4);
-  const int grid = grid_for64(tiles, std::max(1, 2048 / nvec));
+  static const int cap_col = env_int64("NTTX_GRID_COL64", 1 << 20);   // one tile per workgroup, as on the 32-bit path
+  const int grid = grid_for64(tiles, std::max(1, cap_col / nvec));
 #define NTTX_COL64_CASE(K) case K: \
     hipLaunchKernelGGL((col64_kernel<K, INV, SAFE, PLO1, ZHI>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
   switch (logT) {

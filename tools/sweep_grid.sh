@@ -7,6 +7,8 @@ for g in "$@"; do
 import json, sys
 d = json.loads(open("gpurun_out/_s.log").readline())
 print("crt", sys.argv[1], sys.argv[2], round(d["us_per_mult"], 3), d["kernels_ms_per_step"])
+d = json.loads(open("gpurun_out/_s.log").readlines()[1])
+print("direct64", sys.argv[1], sys.argv[2], round(d["us_per_mult"], 3), d["kernels_ms_per_step"])
 PY
   env $knob=$g timeout -k 10 200 python bench.py --no-cpu > gpurun_out/_s.log 2>/dev/null || exit 1
   python - "$knob" "$g" <<'PY' >> gpurun_out/sweep_grid.log
