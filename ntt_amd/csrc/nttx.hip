@@ -253,7 +253,8 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
 #define NTTX_ROW_CASE(K) case K: { \
     using Lyt = RowLayout<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    hipLaunchKernelGGL((row_kernel<K, MODE, H>), dim3(grid_for(tiles, 8192)), dim3(WG), 0, st, A); break; }
+    hipLaunchKernelGGL((row_kernel<K, MODE, H>), dim3(grid_for(tiles, capg)), dim3(WG), 0, st, A); break; }
+  static const int capg = env_int("NTTX_GRID_ROWG", 8192);
   switch (logT) {
     NTTX_ROW_CASE(1) NTTX_ROW_CASE(2) NTTX_ROW_CASE(3) NTTX_ROW_CASE(4) NTTX_ROW_CASE(5) NTTX_ROW_CASE(6)
     NTTX_ROW_CASE(7) NTTX_ROW_CASE(8) NTTX_ROW_CASE(9) NTTX_ROW_CASE(10) NTTX_ROW_CASE(11)
