@@ -64,6 +64,8 @@ struct Plan {
   uint32_t *tw_inv[3] = {nullptr, nullptr, nullptr};  // same for w^{-1}
   uint32_t *fs_fwd[2] = {nullptr, nullptr};           // four-step tables per column pass
   uint32_t *fs_inv[2] = {nullptr, nullptr};           // inverse; level 0 also carries n^{-1} R
+  // three-pass lengths: the outer pass's factors as a product of two small tables (fs_* = low part)
+  uint32_t *fsa_fwd = nullptr, *fsa_inv = nullptr; int logC2 = 0;
   uint32_t scale_single = 0;                          // n^{-1} R^2 mod p (single-pass products)
   ~Plan() {
     for (auto q : tw_fwd) if (q) (void)hipFree(q);
@@ -226,8 +228,19 @@ static int get_plan(Context *cx, uint32_t p, int logL, bool conj, Plan **out) {
     if (int rc = upload(&pl->tw_inv[lv], stage_table(wTi, lt, pl->ctx))) return rc;
     if (lv < pl->npass - 1) {
       const int logS = logN - lt;
-      if (int rc = upload(&pl->fs_fwd[lv], fourstep_table(wN, lt, logS, 1, pl->ctx))) return rc;
-      if (int rc = upload(&pl->fs_inv[lv], fourstep_table(wNi, lt, logS, lv == 0 ? ninvR : 1, pl->ctx))) return rc;
+      if (lv == 0 && pl->npass == 3) {
+        // w^(s r) = w^(h C r) * w^(l r) for s = h C + l: T*(S/C + C) words instead of T*S
+        const int c2 = (logS + 1) / 2;
+        pl->logC2 = c2;
+        const uint32_t wC = h_powmod(wN, 1ull << c2, p), wCi = h_powmod(wNi, 1ull << c2, p);
+        if (int rc = upload(&pl->fs_fwd[lv], fourstep_table(wN, lt, c2, 1, pl->ctx))) return rc;
+        if (int rc = upload(&pl->fs_inv[lv], fourstep_table(wNi, lt, c2, 1, pl->ctx))) return rc;
+        if (int rc = upload(&pl->fsa_fwd, fourstep_table(wC, lt, logS - c2, 1, pl->ctx))) return rc;
+        if (int rc = upload(&pl->fsa_inv, fourstep_table(wCi, lt, logS - c2, ninvR, pl->ctx))) return rc;
+      } else {
+        if (int rc = upload(&pl->fs_fwd[lv], fourstep_table(wN, lt, logS, 1, pl->ctx))) return rc;
+        if (int rc = upload(&pl->fs_inv[lv], fourstep_table(wNi, lt, logS, lv == 0 ? ninvR : 1, pl->ctx))) return rc;
+      }
       logN = logS;
     }
   }
@@ -276,7 +289,7 @@ static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream
 
 // Column tile shape: 32 columns (full 128-byte lines) with 512 threads where the tile fits LDS
 // comfortably, 16 columns with 256 threads for the longest column passes.
-template <bool INV, int H, bool ZHI>
+template <bool INV, int H, bool ZHI, bool FS2>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
   const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
@@ -289,7 +302,16 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int g16 = (grid_for(tiles, cap) + 15) / 16 * 16;
   const int grid = g16 <= tiles ? g16 : grid_for(tiles, cap);
 #define NTTX_COL_CASE(K, LC, NT) \
-    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, FS2>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+  if constexpr (FS2) {
+    switch (logT * 2 + wide) {
+      case 15: NTTX_COL_CASE(7, 5, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
+      case 19: NTTX_COL_CASE(9, 5, 512)   case 20: NTTX_COL_CASE(10, 4, 256)   // 512 threads: the 1024-thread shape has no registers left for the second factor
+      default: return fail(NTTX_ERANGE, "split-table column pass of 2^%d points unsupported", logT);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   switch (logT * 2 + wide) {
     case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
     case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
@@ -304,8 +326,11 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
 }
 template <bool INV, bool ZHI>
 static int launch_col_i(int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  return h == 9 ? launch_col_t<INV, 9, ZHI>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4, ZHI>(logT, A, nvec, st)
-                                                                        : launch_col_t<INV, 2, ZHI>(logT, A, nvec, st);
+  if (A.fsa)
+    return h == 9 ? launch_col_t<INV, 9, ZHI, true>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4, ZHI, true>(logT, A, nvec, st)
+                                                                                : launch_col_t<INV, 2, ZHI, true>(logT, A, nvec, st);
+  return h == 9 ? launch_col_t<INV, 9, ZHI, false>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4, ZHI, false>(logT, A, nvec, st)
+                                                                               : launch_col_t<INV, 2, ZHI, false>(logT, A, nvec, st);
 }
 // A.nvalid > 0 selects the zero-padded-half forward variant (needs nvalid <= N/2)
 static int launch_col_raw(bool inv, int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
@@ -370,6 +395,7 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
   for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
     ColArgs C{}; C.in[0] = lv == 0 ? a : wa; C.in[1] = lv == 0 ? b : wb; C.out[0] = wa; C.out[1] = wb;
     C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
+    if (lv == 0) { C.fsa = pl->fsa_fwd; C.logC2 = pl->logC2; }
     C.nblocks = ((long long)batch << pl->logL) >> logN;
     C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
     if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, st)) return rc;
@@ -384,6 +410,7 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
     ColArgs C{}; C.in[0] = c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
     C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
+    if (lv == 0) { C.fsa = pl->fsa_inv; C.logC2 = pl->logC2; }
     C.nblocks = ((long long)batch << pl->logL) >> logNl;
     if (int rc = launch_col(cx, true, pl->hclass, pl->lt[lv], C, 1, st)) return rc;
   }
@@ -396,6 +423,7 @@ static int dev_forward(Context *cx, Plan *pl, uint32_t *x, int batch, bool canon
   const int ncol = pl->npass - 1;
   for (int lv = 0; lv < ncol; ++lv) {
     ColArgs C{}; C.in[0] = x; C.out[0] = x; C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx;
+    if (lv == 0) { C.fsa = pl->fsa_fwd; C.logC2 = pl->logC2; }
     C.logS = logN - pl->lt[lv]; C.canon_out = 0; C.nblocks = ((long long)batch << pl->logL) >> logN;
     if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 1, st)) return rc;
     logN = C.logS;

@@ -530,7 +530,9 @@ struct ColArgs {
   const uint32_t *in[2];
   uint32_t *out[2];
   const uint32_t *tw;     // stage-major table for T (forward or inverse root)
-  const uint32_t *fs;     // four-step table, N words
+  const uint32_t *fs;     // four-step table, N words (FS2 kernels: the low-part table, T x 2^logC2 words)
+  const uint32_t *fsa;    // FS2 kernels: the high-part table, T x S/2^logC2 words
+  int logC2;
   PrimeCtx ctx;
   int logS;               // S = 2^logS >= columns per tile
   int canon_out;
@@ -543,7 +545,10 @@ struct ColArgs {
 // current tile start, so HBM latency overlaps with compute inside one workgroup.
 // ZHI (forward only): each block is a zero-padded vector whose first nvalid <= N/2 words hold data.
 // Rows from T/2 on are never read (half the input traffic) and the first butterfly stage degenerates.
-template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false>
+// FS2: the four-step factor of column s = h 2^logC2 + l is the product fsa[j][h] * fs[j][l] of two
+// small tables (one more multiplication per point) instead of an N-word table read: for the long
+// outer pass of three-pass lengths, where that table would double the pass's HBM traffic.
+template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false>
 __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColArgs A) {
   using L = ColLayout<LOGT, LOGC, NTHR>;
   constexpr int T = L::T, COLS = L::COLS;
@@ -571,6 +576,21 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     return (blk << (logS + LOGT)) + (ct << LOGC);
   };
   auto fs_base = [&](long long t) -> long long { return (t & ((1ll << log_tpb) - 1)) << LOGC; };
+  // x * (four-step factor of row j, columns fbase + c4 .. + 3)
+  auto fs_mul = [&](uint4 &x, long long fbase, int j) {
+    uint4 f;
+    if constexpr (!FS2) {
+      f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
+    } else {
+      const long long s0 = fbase + c4;
+      f = *reinterpret_cast<const uint4 *>(A.fs + ((long long)j << A.logC2) + (s0 & ((1ll << A.logC2) - 1)));
+      const uint32_t fa = A.fsa[((long long)j << (logS - A.logC2)) + (s0 >> A.logC2)];
+      x.x = M.mul(V<Arith<H>::KANY>{x.x}, fa).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, fa).v;
+      x.z = M.mul(V<Arith<H>::KANY>{x.z}, fa).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, fa).v;
+    }
+    x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
+    x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
+  };
 
   // one 16-byte piece of the tile at row j; ZHI masks words at or beyond nvalid of the block
   auto load_piece = [&](long long base, long long t_, int j) -> uint4 {
@@ -611,11 +631,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     for (int k = 0; k < PERL; ++k) {
       uint4 x = nx[k];
       const int j = j0 + k * RSTEP;
-      if (INV) {
-        const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
-        x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
-        x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
-      }
+      if (INV) fs_mul(x, fbase, j);
       *reinterpret_cast<uint4 *>(s + L::addr(c4, j)) = x;
     }
     if (t0 + gridDim.x < ntiles) {
@@ -635,11 +651,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     for (int k = 0; k < PER; ++k) {
       const int j = j0 + k * RSTEP;
       uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c4, j));
-      if (!INV) {
-        const uint4 f = *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
-        x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
-        x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
-      }
+      if (!INV) fs_mul(x, fbase, j);
       if (A.canon_out) {   // forward results are < 2p after the multiply, inverse results < KI*p
         x.x = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.x}); x.y = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.y});
         x.z = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.z}); x.w = M.canon(V<(INV ? Arith<H>::KI : 2)>{x.w});
