@@ -78,10 +78,11 @@ struct Plan {
 // Tables of one column pass over a slab of columns (a transform shared by several processes):
 // the stage table of the length-T column transforms and the four-step factors of the slab.
 struct Slab {
-  uint32_t *tw = nullptr, *fs = nullptr;
+  uint32_t *tw = nullptr, *fs = nullptr, *fsa = nullptr;   // fsa != null: factors split over two tables
+  int logC2 = 0;
   PrimeCtx ctx{};
   int hclass = 2;
-  ~Slab() { if (tw) (void)hipFree(tw); if (fs) (void)hipFree(fs); }
+  ~Slab() { if (tw) (void)hipFree(tw); if (fs) (void)hipFree(fs); if (fsa) (void)hipFree(fsa); }
 };
 
 constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
@@ -595,7 +596,17 @@ static int get_slab(Context *cx, uint32_t p, int logL, int logT, long long col0,
   const uint32_t wT = h_powmod(wL, 1ull << (logL - logT), p);
   const uint32_t tinv = h_powmod((uint32_t)((1ull << logT) % p), p - 2, p);
   if (int rc = upload(&sl->tw, stage_table(wT, logT, sl->ctx))) return rc;
-  if (int rc = upload(&sl->fs, fourstep_table(wL, logT, logC, inverse ? tinv : 1, sl->ctx, (uint64_t)col0))) return rc;
+  const bool split_ok = logC >= 13 && (logT == 10 || (logT >= 7 && logT <= 9));   // shapes with a split-table kernel
+  if (split_ok) {
+    // w^((col0 + s) r) with s = h C + l and col0 a multiple of C: (w^C)^((col0/C + h) r) * w^(l r)
+    const int c2 = (logC + 1) / 2;
+    sl->logC2 = c2;
+    const uint32_t wC = h_powmod(wL, 1ull << c2, p);
+    if (int rc = upload(&sl->fs, fourstep_table(wL, logT, c2, 1, sl->ctx))) return rc;
+    if (int rc = upload(&sl->fsa, fourstep_table(wC, logT, logC - c2, inverse ? tinv : 1, sl->ctx, (uint64_t)col0 >> c2))) return rc;
+  } else {
+    if (int rc = upload(&sl->fs, fourstep_table(wL, logT, logC, inverse ? tinv : 1, sl->ctx, (uint64_t)col0))) return rc;
+  }
   *out = sl.get();
   cx->slabs[key] = std::move(sl);
   return 0;
@@ -611,7 +622,7 @@ static int dev_colpass(Context *cx, uint32_t *d_x, int logL, int logT, long long
     return fail(NTTX_EINVAL, "slab must be a power-of-two number (>= 16) of columns aligned to its own width");
   Slab *sl;
   if (int rc = get_slab(cx, p, logL, logT, col0, logC, inverse, &sl)) return rc;
-  ColArgs C{}; C.in[0] = d_x; C.out[0] = d_x; C.tw = sl->tw; C.fs = sl->fs; C.ctx = sl->ctx; C.logS = logC;
+  ColArgs C{}; C.in[0] = d_x; C.out[0] = d_x; C.tw = sl->tw; C.fs = sl->fs; C.fsa = sl->fsa; C.logC2 = sl->logC2; C.ctx = sl->ctx; C.logS = logC;
   C.canon_out = 1; C.nblocks = 1;
   C.nvalid = (!inverse && zero_hi) ? ((1ll << logT) / 2) * cols : 0;
   return launch_col(cx, inverse, sl->hclass, logT, C, 1, st);

@@ -128,10 +128,12 @@ def test_fourstep_sharded_vs_oracle(nttx, oracle, p, log_len, log_t, world, line
     assert np.array_equal(full, want)
 
 
-def test_fourstep_sharded_large_vs_single_gpu(nttx, oracle):
-    """Length 2^22 over 4 in-process ranks equals the single-GPU three-pass product bit for bit."""
+@pytest.mark.parametrize("log_len,world", [(22, 4), (24, 2), (25, 4)])
+def test_fourstep_sharded_large_vs_single_gpu(nttx, oracle, log_len, world):
+    """Long products over in-process ranks equal the single-GPU three-pass product bit for bit
+    (2^24 / 2 ranks and 2^25 / 4 ranks have slabs of 2^14 columns: the split-table column pass)."""
     from ntt_amd.distributed import FourStepSharded, HipEngine, ThreadComm
-    p, log_len = 469762049, 22
+    p = 469762049
     L = 1 << log_len
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
@@ -152,7 +154,7 @@ def test_fourstep_sharded_large_vs_single_gpu(nttx, oracle):
         torch.cuda.synchronize()
         return None
 
-    ThreadComm.run(4, body)
+    ThreadComm.run(world, body)
     assert torch.equal(full, ref)
     # spot-check against the definition at a few indices (exact integer arithmetic on the host)
     ah, bh = a.cpu().numpy().view(np.uint32).astype(np.uint64), b.cpu().numpy().view(np.uint32).astype(np.uint64)
