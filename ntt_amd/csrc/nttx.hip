@@ -89,7 +89,12 @@ constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 
 static int decompose(int k, int lt[3]) {
   if (k <= kMaxRowLog) { lt[0] = k; return 1; }
-  if (k <= kMaxColLog + kMaxRowLog) { lt[0] = k / 2; lt[1] = k - lt[0]; return 2; }
+  if (k <= kMaxColLog + kMaxRowLog) {
+    // 2^9-point column passes run on full 128-byte tiles; 2^10-point ones only on 64-byte tiles
+    lt[0] = (k - 9 <= kMaxRowLog) ? std::min(9, k / 2) : k / 2;
+    lt[1] = k - lt[0];
+    return 2;
+  }
   int row = (k + 2) / 3; if (row > kMaxRowLog) row = kMaxRowLog;
   int rem = k - row;
   lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
