@@ -136,7 +136,6 @@ struct Profiler {
 struct Context {
   int device = -1;
   Profiler prof;
-  std::mutex mu;
   std::map<std::tuple<uint32_t, int, bool>, std::unique_ptr<Plan>> plans;
   std::map<std::tuple<uint32_t, int, int, long long, int, bool>, std::unique_ptr<struct Slab>> slabs;
   // workspace
@@ -646,9 +645,12 @@ static int fail_from64(int rc) { return rc < 0 ? fail(rc, "%s", engine64_error()
 // =========================================================================================
 using namespace nttx;
 
+// One mutex serialises every call of the process, nttx_init and nttx_shutdown included, so a
+// shutdown cannot pull the context from under a call in flight on another thread.
 #define NTTX_ENTER() \
+  std::lock_guard<std::mutex> lock_(g_init_mu); \
   if (!g_ctx) return fail(NTTX_ENOINIT, "nttx_init has not been called"); \
-  Context *cx = g_ctx; std::lock_guard<std::mutex> lock_(cx->mu); \
+  Context *cx = g_ctx; \
   HIPCHK(hipSetDevice(cx->device));
 
 extern "C" {
