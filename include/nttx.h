@@ -88,6 +88,13 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
 int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch,
                                  void *stream);
 
+/* d_c[b] = d_a[b] * d_b[b] mod (x^len + 1, p): the negacyclic product (wrap-around with a sign
+ * change), [batch][len] u32 arrays as above; needs 2*len | p-1.  No counterpart in the reference,
+ * whose products are always zero-padded (main.cc:278-281); for callers that work in
+ * Z_p[x]/(x^len + 1) and would otherwise pay for a transform of twice the length. */
+int nttx_dev_negacyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch,
+                                     void *stream);
+
 /* Linear product of n-coefficient polynomials held zero-padded in [batch][len] arrays, len the
  * smallest power of two >= 2n (the padding of main.cc:278-281): d_c[b][0..2n-2] = a*b mod p, the
  * rest of d_c[b] is zero.  Words of d_a, d_b at index >= n must be zero and are not read on lengths

@@ -33,6 +33,7 @@ _SIGS = [
     ("nttx_cyclic_multiply_u32", C.c_int, [_u32p, _u32p, _u32p, C.c_int, C.c_uint32]),
     ("nttx_crt_combine_u64", C.c_int, [C.POINTER(_u32p), _u64p, C.c_int, C.c_int, C.c_uint64]),
     ("nttx_dev_cyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
+    ("nttx_dev_negacyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_poly_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_crt_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_dev_ntt_u32", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -191,6 +192,11 @@ def crt_combine(residues, nout: int, p: int):
 # ---- device-resident calls: arguments are raw device pointers (e.g. torch tensor.data_ptr()) ----
 def dev_cyclic_multiply_u32(d_a: int, d_b: int, d_c: int, length: int, p: int, batch: int, stream: int = 0):
     _check(lib().nttx_dev_cyclic_multiply_u32(d_a, d_b, d_c, length, p, batch, stream))
+
+
+def dev_negacyclic_multiply_u32(d_a: int, d_b: int, d_c: int, length: int, p: int, batch: int, stream: int = 0):
+    """c = a*b mod (x^length + 1, p) on [batch][length] u32 device arrays."""
+    _check(lib().nttx_dev_negacyclic_multiply_u32(d_a, d_b, d_c, length, p, batch, stream))
 
 
 def dev_poly_multiply_u32(d_a: int, d_b: int, d_c: int, n: int, p: int, batch: int, stream: int = 0):

@@ -85,6 +85,12 @@ struct Slab {
   ~Slab() { if (tw) (void)hipFree(tw); if (fs) (void)hipFree(fs); if (fsa) (void)hipFree(fsa); }
 };
 
+// psi^i and psi^-i for i < 2^logL, psi a primitive 2^(logL+1)-th root of unity (negacyclic products)
+struct Twist {
+  uint32_t *fwd = nullptr, *inv = nullptr;
+  ~Twist() { if (fwd) (void)hipFree(fwd); if (inv) (void)hipFree(inv); }
+};
+
 constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 
 static int decompose(int k, int lt[3]) {
@@ -138,6 +144,7 @@ struct Context {
   Profiler prof;
   std::map<std::tuple<uint32_t, int, bool>, std::unique_ptr<Plan>> plans;
   std::map<std::tuple<uint32_t, int, int, long long, int, bool>, std::unique_ptr<struct Slab>> slabs;
+  std::map<std::pair<uint32_t, int>, std::unique_ptr<struct Twist>> twists;
   // workspace
   DevBuf wa, wb;            // transformed copies of a and b (multi-pass direct path) [batch][len]
   DevBuf in_a, in_b;        // raw host inputs staged on device
@@ -632,6 +639,55 @@ static int dev_colpass(Context *cx, uint32_t *d_x, int logL, int logT, long long
   return launch_col(cx, inverse, sl->hclass, logT, C, 1, st);
 }
 
+// ---- negacyclic product: c = a*b mod (x^len + 1, p) ---------------------------------------
+// a'(x) = a(psi x), b'(x) = b(psi x) with psi^len = -1 turns the wrap-around sign into the cyclic
+// product's plain wrap-around; c(x) = c'(x / psi).  Three element-wise passes around the cyclic
+// product (no counterpart in the reference, which only multiplies zero-padded polynomials).
+static int get_twist(Context *cx, uint32_t p, int logL, Twist **out) {
+  auto key = std::make_pair(p, logL);
+  auto it = cx->twists.find(key);
+  if (it != cx->twists.end()) { *out = it->second.get(); return 0; }
+  if (!direct_ok(p, logL + 1)) return fail(NTTX_EINVAL, "modulus %u has no 2^%d-th root of unity for a negacyclic product of length 2^%d", p, logL + 1, logL);
+  const PrimeCtx c = make_ctx(p);
+  const uint32_t g = find_nonresidue(p);
+  const uint32_t psi = h_powmod(g, (uint64_t)(p - 1) >> (logL + 1), p), psii = h_powmod(psi, p - 2, p);
+  const size_t len = (size_t)1 << logL;
+  std::vector<uint32_t> f(len), b(len);
+  const uint32_t sf = to_mont(psi, c), sb = to_mont(psii, c);
+  uint32_t cf = c.one, cb = c.one;
+  for (size_t i = 0; i < len; ++i) { f[i] = cf; b[i] = cb; cf = mont_mul(cf, sf, c.p, c.npinv); cb = mont_mul(cb, sb, c.p, c.npinv); }
+  std::unique_ptr<Twist> tw(new Twist);
+  if (int rc = upload(&tw->fwd, f)) return rc;
+  if (int rc = upload(&tw->inv, b)) return rc;
+  *out = tw.get();
+  cx->twists[key] = std::move(tw);
+  return 0;
+}
+
+static int dev_negacyclic_multiply(Context *cx, const uint32_t *a, const uint32_t *b, uint32_t *c, int logL, uint32_t p,
+                                   int batch, hipStream_t st) {
+  Plan *pl; Twist *tw;
+  if (int rc = get_plan(cx, p, logL, false, &pl)) return rc;
+  if (int rc = get_twist(cx, p, logL, &tw)) return rc;
+  const long long len = 1ll << logL;
+  const size_t vec = (size_t)batch * len * 4;
+  if (int rc = cx->pa.ensure(vec)) return rc;
+  if (int rc = cx->pb.ensure(vec)) return rc;
+  TwistArgs T{}; T.src[0] = a; T.src[1] = b; T.dst[0] = cx->pa.as<uint32_t>(); T.dst[1] = cx->pb.as<uint32_t>();
+  T.tab = tw->fwd; T.ctx = pl->ctx; T.len = (int)len;
+  cx->prof.begin(PK_MISC, st);
+  hipLaunchKernelGGL(twist_kernel, ew_grid2(len, batch, 2), dim3(256), 0, st, T);
+  cx->prof.end(st);
+  HIPCHK(hipGetLastError());
+  if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), c, batch, st)) return rc;
+  TwistArgs U{}; U.src[0] = c; U.dst[0] = c; U.tab = tw->inv; U.ctx = pl->ctx; U.len = (int)len;
+  cx->prof.begin(PK_MISC, st);
+  hipLaunchKernelGGL(twist_kernel, ew_grid2(len, batch, 1), dim3(256), 0, st, U);
+  cx->prof.end(st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ---- 64-bit-lane direct path (nttx64.hip) ------------------------------------------------
 static void prof64_begin(void *self, int kind, hipStream_t st) { static_cast<Profiler *>(self)->begin(kind, st); }
 static void prof64_end(void *self, hipStream_t st) { static_cast<Profiler *>(self)->end(st); }
@@ -680,6 +736,7 @@ void nttx_shutdown(void) {
   (void)hipDeviceSynchronize();
   g_ctx->plans.clear();
   g_ctx->slabs.clear();
+  g_ctx->twists.clear();
   engine64_destroy(g_ctx->e64);
   g_ctx->prof.destroy();
   for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
@@ -746,6 +803,13 @@ int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, in
   Plan *pl;
   if (int rc = get_plan(cx, p, k, false, &pl)) return rc;
   return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch, (hipStream_t)stream);
+}
+
+int nttx_dev_negacyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_c || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
+  int k = 0; while ((1ll << k) < len) ++k;
+  return dev_negacyclic_multiply(cx, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, k, p, batch, (hipStream_t)stream);
 }
 
 int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch, void *stream) {

@@ -742,6 +742,23 @@ __global__ void pad_kernel(PadArgs A) {
   }
 }
 
+// dst[z][b][i] = src[z][b][i] * tab[i] mod p, canonical (tab in Montgomery form): the psi^i / psi^-i
+// twists that turn a cyclic product into a negacyclic one
+struct TwistArgs {
+  const uint32_t *src[2];
+  uint32_t *dst[2];
+  const uint32_t *tab;
+  PrimeCtx ctx;
+  int len;
+};
+__global__ void twist_kernel(TwistArgs A) {
+  const long long b = blockIdx.y;
+  const uint32_t *src = A.src[blockIdx.z] + b * A.len;
+  uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.len; i += gridDim.x * blockDim.x)
+    dst[i] = mont_mul(src[i], A.tab[i], A.ctx.p, A.ctx.npinv);
+}
+
 // gather the first nout words of every length-len vector (u32 -> u32 or u64)
 template <class OUT>
 __global__ void unpad_kernel(const uint32_t *src, OUT *dst, int nout, int len) {

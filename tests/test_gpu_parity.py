@@ -304,3 +304,27 @@ def test_device_linear_product_skips_padding(nttx, oracle, n):
         want = oracle.poly_multiply_crt(a[i, :n].astype(np.uint64), b[i, :n].astype(np.uint64), p)
         assert np.array_equal(c[i, :2 * n - 1].astype(np.uint64), want), (n, i)
         assert not c[i, 2 * n - 1:].any()
+
+
+@pytest.mark.parametrize("p,log_len,batch", [(469762049, 3, 2), (998244353, 10, 3), (1224736769, 13, 2), (469762049, 18, 2)])
+def test_negacyclic_product(nttx, oracle, p, log_len, batch):
+    """c = a b mod (x^len + 1, p): equals lin[i] - lin[i + len] of the linear product, which the
+    oracle gives as a cyclic product of the zero-padded inputs (ntt_compute, main.cc:185-209)."""
+    import torch
+    L = 1 << log_len
+    a = np.stack([oracle.fill_random(L, 300 + i, p) for i in range(batch)]).astype(np.uint32)
+    b = np.stack([oracle.fill_random(L, 400 + i, p) for i in range(batch)]).astype(np.uint32)
+    da, db = torch.from_numpy(a.view(np.int32)).cuda(), torch.from_numpy(b.view(np.int32)).cuda()
+    dc = torch.empty_like(da)
+    nttx.dev_negacyclic_multiply_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), L, p, batch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy().view(np.uint32)
+    for i in range(batch):
+        pa, pb = np.zeros(2 * L, dtype=np.uint32), np.zeros(2 * L, dtype=np.uint32)
+        pa[:L], pb[:L] = a[i], b[i]
+        lin = oracle.ntt_compute(pa, pb, p).astype(np.int64)
+        want = (lin[:L] - lin[L:]) % p
+        assert np.array_equal(got[i].astype(np.int64), want), (p, log_len, i)
+    assert torch.equal(da.cpu(), torch.from_numpy(a.view(np.int32)))     # inputs untouched
+    with pytest.raises(nttx.NttxError):                                  # 7340033 - 1 = 7 * 2^20: no 2^21-th root
+        nttx.dev_negacyclic_multiply_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), 1 << 20, 7340033, 1, 0)
