@@ -189,7 +189,9 @@ static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
 #define NTTX_ROW64_CASE(K) case K: { \
     using Lyt = RowLayout64<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap_row)), dim3(256), 0, st, A); break; }
+    if constexpr (MODE == 2) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap_row)), dim3(256), 0, st, A); \
+    else hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap_row)), dim3(256), 0, st, A); \
+    break; }
   static const int cap_row = env_int64("NTTX_GRID_ROW64", 4096);
   switch (logT) {
     NTTX_ROW64_CASE(1) NTTX_ROW64_CASE(2) NTTX_ROW64_CASE(3) NTTX_ROW64_CASE(4) NTTX_ROW64_CASE(5) NTTX_ROW64_CASE(6)

@@ -25,6 +25,13 @@ namespace nttx {
 // 19*2^46+1): word-serial REDC with radix 2^32, where -p^-1 mod 2^32 = -1 and p's low word
 // is 1, so each of the two reduction steps is one negation and one 32x32 multiply:
 // six v_mad_u64_u32 in all.  Otherwise the two-multiply-high form is used.
+// 1 if x != 0 else 0, as one v_min_u32 (the compiler's compare + select pair issues far slower)
+__device__ __forceinline__ uint32_t nonzero32(uint32_t x) {
+  uint32_t r;
+  asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 template <bool PLO1>
 __device__ __forceinline__ uint64_t mont64_lazy(uint64_t x, uint64_t w, uint64_t p, uint64_t npinv) {
   if constexpr (PLO1) {
@@ -34,14 +41,14 @@ __device__ __forceinline__ uint64_t mont64_lazy(uint64_t x, uint64_t w, uint64_t
     const uint32_t a0 = (uint32_t)u;
     const uint64_t v = (uint64_t)x0 * w1 + (u >> 32);                         // words 1..2 of x0*w
     const uint32_t m = 0u - a0;                                               // a0 + m = 2^32 * (a0 != 0)
-    const uint64_t v2 = (uint64_t)m * ph + ((uint64_t)(uint32_t)v + (a0 != 0 ? 1u : 0u));
+    const uint64_t v2 = (uint64_t)m * ph + ((uint64_t)(uint32_t)v + nonzero32(a0));
     const uint32_t b1 = (uint32_t)(v >> 32) + (uint32_t)(v2 >> 32);           // (x0*w + m*p) / 2^32 < 2^63
     const uint32_t b0 = (uint32_t)v2;
     const uint64_t u2 = (uint64_t)x1 * w0 + b0;
     const uint32_t c0 = (uint32_t)u2;
     const uint64_t v3 = (uint64_t)x1 * w1 + ((uint64_t)b1 + (u2 >> 32));
     const uint32_t m2 = 0u - c0;
-    const uint64_t v4 = (uint64_t)m2 * ph + ((uint64_t)(uint32_t)v3 + (c0 != 0 ? 1u : 0u));
+    const uint64_t v4 = (uint64_t)m2 * ph + ((uint64_t)(uint32_t)v3 + nonzero32(c0));
     const uint32_t d1 = (uint32_t)(v3 >> 32) + (uint32_t)(v4 >> 32);
     return ((uint64_t)d1 << 32) | (uint32_t)v4;
   } else {
@@ -281,6 +288,100 @@ __global__ void __launch_bounds__(256) row64_kernel(RowArgs64 A) {
       uint64_t *const v[1] = {sa};
       dit_rounds64<L, LOGT, AR, 1>(v, twi, M);
     }
+    __syncthreads();
+    constexpr int NV2 = L::NT * T / 2;
+    for (int v = threadIdx.x; v < NV2; v += L::NTHR) {
+      const int c = (v * 2) >> LOGT, j = (v * 2) & (T - 1);
+      if (row0 + c < A.nrows) {
+        ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(sa + L::addr(c, j));
+        if (A.canon_out) { x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one); }
+        *reinterpret_cast<ulonglong2 *>(A.out + (row0 + c) * T + j) = x;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Fused product on rows: forward a, forward b, pointwise, inverse, through ONE LDS buffer.
+// The last forward round, the pointwise product and the first inverse round all act on the
+// same 8 points of a thread (units at distance 1), so a's and b's transformed values wait in
+// registers while the other vector uses the buffer: half the LDS of keeping both vectors
+// resident (twice the workgroups per CU) and two LDS round trips fewer.
+// ------------------------------------------------------------------------------------
+// all rounds of a forward pass but the last (which has R = RL stages at distance 1)
+template <class L, int REM, class AR>
+__device__ __forceinline__ void dif_head64(uint64_t *s, const uint64_t *tw, const AR &M) {
+  if constexpr (REM > 3) {
+    uint64_t *const v[1] = {s};
+    ntt_round64<L, 3, REM - 3, false, AR, 1, false>(v, tw, M);
+    __syncthreads();
+    dif_head64<L, REM - 3, AR>(s, tw, M);
+  }
+}
+// all rounds of an inverse pass after the first
+template <class L, int REM, class AR>
+__device__ __forceinline__ void dit_tail64(uint64_t *s, const uint64_t *tw, const AR &M) {
+  if constexpr (REM > 3) {
+    dit_tail64<L, REM - 3, AR>(s, tw, M);
+    __syncthreads();
+    uint64_t *const v[1] = {s};
+    ntt_round64<L, 3, REM - 3, true, AR, 1, false>(v, tw, M);
+  }
+}
+// the distance-1 round on registers: r[u*NP + q] = point q of the thread's u-th unit
+template <class L, int RL, bool INV, bool LOAD, bool STORE, class AR>
+__device__ __forceinline__ void edge_round64(uint64_t *s, const uint64_t *tw, const AR &M, uint64_t (&r)[8]) {
+  constexpr int NP = 1 << RL, NU = 8 / NP;
+  constexpr int LOG_UNITS = L::LOGT - RL;
+  static_assert((L::NT << LOG_UNITS) == NU * L::NTHR, "eight points per thread");
+  uint64_t w[NP];
+  w[0] = 0;
+#pragma unroll
+  for (int m = 1; m < NP; ++m) w[m] = tw[m];     // distance 1: lo = 0
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int g = threadIdx.x + u * L::NTHR;
+    int c, un;
+    L::template split<LOG_UNITS>(g, c, un);
+    const int a0 = L::addr(c, un << RL);
+    uint64_t x[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) x[q] = LOAD ? s[a0 + L::padj(q)] : r[u * NP + q];
+    unit64<RL, INV, true, false, AR>(x, w, M, INV ? 0 : L::LOGT - RL);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { if (STORE) s[a0 + L::padj(q)] = x[q]; else r[u * NP + q] = x[q]; }
+  }
+}
+
+template <int LOGT, bool SAFE, bool PLO1>
+__global__ void __launch_bounds__(256) rowmul64_kernel(RowArgs64 A) {
+  using L = RowLayout64<LOGT>;
+  using AR = Arith64<SAFE, PLO1>;
+  constexpr int T = L::T;
+  constexpr int RL = (LOGT - 1) % 3 + 1;          // stages of the distance-1 round
+  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + 2 * T];
+  uint64_t *sa = lds, *twf = lds + L::WORDS, *twi = twf + T;
+  const AR M(A.ctx);
+  for (int i = threadIdx.x; i < T; i += L::NTHR) { twf[i] = A.tw_fwd[i]; twi[i] = A.tw_inv[i]; }
+
+  for (long long row0 = (long long)blockIdx.x * L::NT; row0 < A.nrows; row0 += (long long)gridDim.x * L::NT) {
+    uint64_t ra[8], rb[8];
+    __syncthreads();
+    row_load64<L>(sa, A.in0, row0, A.nrows);
+    __syncthreads();
+    dif_head64<L, LOGT, AR>(sa, twf, M);
+    edge_round64<L, RL, false, true, false, AR>(sa, twf, M, ra);
+    __syncthreads();
+    row_load64<L>(sa, A.in1, row0, A.nrows);
+    __syncthreads();
+    dif_head64<L, LOGT, AR>(sa, twf, M);
+    edge_round64<L, RL, false, true, false, AR>(sa, twf, M, rb);
+    // pointwise: (a * pre) is below 2p whatever a held, so its product with b (< 2^12 p) fits REDC
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ra[k] = M.mul(M.mul(ra[k], A.pre), rb[k]);
+    edge_round64<L, RL, true, false, true, AR>(sa, twi, M, ra);
+    __syncthreads();
+    dit_tail64<L, LOGT, AR>(sa, twi, M);
     __syncthreads();
     constexpr int NV2 = L::NT * T / 2;
     for (int v = threadIdx.x; v < NV2; v += L::NTHR) {
