@@ -307,6 +307,62 @@ __device__ __forceinline__ void dit_rounds(uint32_t *const (&s)[NV], const uint3
   }
 }
 
+// Fused product on a tile: the last forward round, the pointwise product and the first inverse round
+// all act on the same 2^RL points at distance 1 of a thread's units, so they run on registers
+// between the LDS-exchanged rounds (saves two barriers and three LDS passes per product).
+template <class L, int REM, int H>
+__device__ __forceinline__ void dif_head(uint32_t *const (&s)[2], const uint32_t *tw, const Arith<H> &M) {
+  constexpr int KF = Arith<H>::KF;
+  if constexpr (REM > 3) {
+    ntt_round<L, 3, REM - 3, false, H, 2, false, KF, KF>(s, tw, M);   // inputs below 2p = KF*p
+    __syncthreads();
+    dif_head<L, REM - 3, H>(s, tw, M);
+  }
+}
+template <class L, int REM, int H>
+__device__ __forceinline__ void dit_tail(uint32_t *const (&s)[1], const uint32_t *tw, const Arith<H> &M) {
+  constexpr int KI = Arith<H>::KI;
+  if constexpr (REM > 3) {
+    dit_tail<L, REM - 3, H>(s, tw, M);
+    __syncthreads();
+    ntt_round<L, 3, REM - 3, true, H, 1, false, KI, KI>(s, tw, M);
+  }
+}
+template <class L, int RL, int H>
+__device__ __forceinline__ void edge_product(uint32_t *sa, const uint32_t *sb, const uint32_t *twf, const uint32_t *twi,
+                                             const Arith<H> &M, uint32_t scale) {
+  constexpr int NP = 1 << RL;
+  constexpr int LOG_UNITS = L::LOGT - RL;
+  constexpr int TOTAL = L::NT << LOG_UNITS;
+  constexpr int KF = Arith<H>::KF, KI = Arith<H>::KI, KP = Arith<H>::KP;
+  uint32_t wf[NP], wi[NP];
+  wf[0] = wi[0] = 0;
+#pragma unroll
+  for (int m = 1; m < NP; ++m) { wf[m] = twf[m]; wi[m] = twi[m]; }
+  for (int g = threadIdx.x; g < TOTAL; g += L::NTHR) {
+    int c, u;
+    L::template split<LOG_UNITS>(g, c, u);
+    const int a0 = L::addr(c, u << RL);
+    uint32_t xa[NP], xb[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { xa[q] = sa[a0 + L::padj(q)]; xb[q] = sb[a0 + L::padj(q)]; }
+    if constexpr (RL == 3) { r8_dif<H, true, false, KF, KP>(xa, wf, M); r8_dif<H, true, false, KF, KP>(xb, wf, M); }
+    else if constexpr (RL == 2) { r4_unit<H, true, false, KF, KP>(xa, wf, M); r4_unit<H, true, false, KF, KP>(xb, wf, M); }
+    else { r2_unit<H, true, false, KF, KP>(xa, wf, M); r2_unit<H, true, false, KF, KP>(xb, wf, M); }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      V<2> pr = M.mul2(V<KP>{xa[q]}, V<KP>{xb[q]});
+      if (scale) pr = M.mul(pr, scale);
+      xa[q] = pr.v;
+    }
+    if constexpr (RL == 3) r8_dit<H, true, 2, KI>(xa, wi, M);
+    else if constexpr (RL == 2) r4_unit<H, true, true, 2, KI>(xa, wi, M);
+    else r2_unit<H, true, true, 2, KI>(xa, wi, M);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) sa[a0 + L::padj(q)] = xa[q];
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Row kernels: transforms are contiguous runs of T words.
 // ------------------------------------------------------------------------------------
@@ -385,7 +441,7 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
     row_load<L>(sa, A.in0, row0, A.nrows);
     if (MODE == ROW_MUL) row_load<L>(sb, A.in1, row0, A.nrows);
     __syncthreads();
-    constexpr int KFc = Arith<H>::KF, KIc = Arith<H>::KI, KPc = Arith<H>::KP;
+    constexpr int KFc = Arith<H>::KF, KIc = Arith<H>::KI;
     if (MODE == ROW_FWD) {         // inputs canonical or fresh from a constant multiply (< 2p)
       uint32_t *const v[1] = {sa};
       dif_rounds<L, LOGT, H, 1, false, KFc, KIc>(v, twf, M);
@@ -393,20 +449,13 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
       uint32_t *const v[1] = {sa};
       dit_rounds<L, LOGT, H, 1, KIc, KIc>(v, twi, M);
     } else {
+      constexpr int RL = (LOGT - 1) % 3 + 1;    // stages of the distance-1 round
       uint32_t *const v2[2] = {sa, sb};
-      dif_rounds<L, LOGT, H, 2, false, KFc, KPc>(v2, twf, M);
-      __syncthreads();
-      // pointwise product (plus the optional n^{-1} R^2 factor), into sa
-      for (int i = threadIdx.x; i < L::NT * T; i += WG) {
-        const int c = i >> LOGT, j = i & (T - 1);
-        const int ad = L::addr(c, j);
-        V<2> pr = M.mul2(V<KPc>{sa[ad]}, V<KPc>{sb[ad]});
-        if (A.scale) pr = M.mul(pr, A.scale);
-        sa[ad] = pr.v;
-      }
-      __syncthreads();
+      dif_head<L, LOGT, H>(v2, twf, M);
+      edge_product<L, RL, H>(sa, sb, twf, twi, M, A.scale);   // + pointwise (and the optional n^{-1} R^2 factor)
+      if constexpr (LOGT > 3) __syncthreads();
       uint32_t *const v[1] = {sa};
-      dit_rounds<L, LOGT, H, 1, 2, KIc>(v, twi, M);
+      dit_tail<L, LOGT, H>(v, twi, M);
     }
     __syncthreads();
     row_store<L, H>(sa, A.out, row0, A.nrows, M, A.canon_out != 0);
