@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: NTT polynomial multiplication at product length 2^18 on MI355X.
 
-Workload (BASELINE.json configs[1]): single 32-bit prime 469762049, n = 2^17 coefficients
+Workload (the single-prime configuration the headline metric is quoted on): prime 469762049, n = 2^17 coefficients
 per input (product length L = 2^18), a batch of independent multiplications resident in
 HBM.  A "step" is one pass of the hot path over the whole batch (batch multiplications).
 With N GPUs every rank runs its own batch (weak scaling, no data-path collective).

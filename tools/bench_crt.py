@@ -1,4 +1,4 @@
-"""Throughput of the 4-prime CRT path (BASELINE config 3) on resident u64 inputs:
+"""Throughput of the 4-prime CRT path on resident u64 inputs:
 n = 2^17 coefficients, p = 1337006139375617 (harness id 4), batch of independent products."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
