@@ -642,10 +642,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
   };
 
   // one 16-byte piece of the tile at row j; ZHI masks words at or beyond nvalid of the block
+  const bool ragged = ZHI && A.nvalid != ((long long)(T / 2) << logS);
   auto load_piece = [&](long long base, long long t_, int j) -> uint4 {
     if constexpr (!ZHI) {
       return *reinterpret_cast<const uint4 *>(in + base + ((long long)j << logS) + c4);
     } else {
+      // every loaded piece lies in a row below T/2; when exactly the lower half holds data no word needs masking
+      if (!ragged) return *reinterpret_cast<const uint4 *>(in + base + ((long long)j << logS) + c4);
       const long long ct = t_ & ((1ll << log_tpb) - 1);
       const long long w0 = ((long long)j << logS) + (ct << LOGC) + c4;   // word index inside the block
       uint4 x = make_uint4(0, 0, 0, 0);
