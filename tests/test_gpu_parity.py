@@ -328,3 +328,28 @@ def test_negacyclic_product(nttx, oracle, p, log_len, batch):
     assert torch.equal(da.cpu(), torch.from_numpy(a.view(np.int32)))     # inputs untouched
     with pytest.raises(nttx.NttxError):                                  # 7340033 - 1 = 7 * 2^20: no 2^21-th root
         nttx.dev_negacyclic_multiply_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), 1 << 20, 7340033, 1, 0)
+
+
+def test_fuzz_small_products(nttx, oracle):
+    """Seeded sweep over ragged lengths and every route: 32-bit-lane, 64-bit-lane and CRT moduli
+    (prime, composite, even), int and uint64 flavours, against the oracle's schoolbook product."""
+    rng = np.random.default_rng(20240607)
+    moduli = [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769, 2147483647, 1000000007,
+              1337006139375617, 263882790666241, 8588886017, 4611685941117976577, 2305843009146585089,
+              281474976710597, 97, 2, 65536, 12345678, (1 << 61) - 1, 3 << 40]
+    big_m = 469762049 * 998244353 * 1004535809 * 1224736769
+    done = 0
+    for _ in range(260):
+        p = moduli[int(rng.integers(len(moduli)))]
+        n = int(rng.integers(1, 700))
+        if nttx.path_for(p, n) == nttx.PATH_CRT4 and n * (p - 1) ** 2 >= big_m:
+            continue
+        a, b = rand(oracle, n, int(rng.integers(1 << 30)), p), rand(oracle, n, int(rng.integers(1 << 30)), p)
+        want = oracle.poly_multiply_naive_u64(a, b, p)
+        got = nttx.poly_multiply(a, b, n, p, dtype=np.uint64)
+        assert np.array_equal(got, want), (p, n)
+        if p < (1 << 31):
+            g32 = nttx.poly_multiply(a.astype(np.int32), b.astype(np.int32), n, p, dtype=np.int32)
+            assert np.array_equal(g32.astype(np.uint64), want), (p, n, "i32")
+        done += 1
+    assert done > 200
