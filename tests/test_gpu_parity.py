@@ -353,3 +353,19 @@ def test_fuzz_small_products(nttx, oracle):
             assert np.array_equal(g32.astype(np.uint64), want), (p, n, "i32")
         done += 1
     assert done > 200
+
+
+def test_fuzz_multi_pass_lengths(nttx, oracle):
+    """Seeded ragged lengths across the one-, two- and three-pass plans (product lengths 2^11 .. 2^22)
+    on the three routes, against the oracle's product (the restatement of main.cc).  Product length
+    2^22 is beyond the reference's prime set (2^21 does not divide 1004535809 - 1 twice over), but with
+    p = 469762049, itself the first CRT prime, its final "mod p" only sees that prime's residue."""
+    rng = np.random.default_rng(77)
+    cases = [(469762049, 11, 22), (1004535809, 11, 21), (263882790666241, 11, 21), (281474976710597, 11, 21)]
+    for p, lo, hi in cases:
+        for k in sorted(set(int(x) for x in rng.integers(lo, hi + 1, size=5)) | {hi}):
+            n = int(rng.integers((1 << (k - 2)) + 1, (1 << (k - 1)) + 1))      # product length exactly 2^k
+            a, b = rand(oracle, n, 900 + k, p), rand(oracle, n, 950 + k, p)
+            want = oracle.poly_multiply_crt(a, b, p)
+            got = nttx.poly_multiply(a, b, n, p, dtype=np.uint64)
+            assert np.array_equal(got, want), (p, n, k)
