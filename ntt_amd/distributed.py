@@ -11,7 +11,7 @@ Two workloads have a real exchange step:
 * `FourStepSharded` - one product too long for a single pass structure to stay on one GPU: the
   vector is a T x S matrix split by columns; column passes are local, a transpose (all-to-all)
   turns column slabs into whole rows, the rows are multiplied locally, and the way back mirrors
-  it: three all-to-alls per product.
+  it: two all-to-alls per product (both inputs travel in the first).
 
 Independent products need no exchange at all; they are sharded with `sharding.shard_range`.
 
@@ -311,12 +311,15 @@ class FourStepSharded:
     def place_slab(self, vec, slab):
         vec.view(self.T, self.S)[:, self.col0: self.col0 + self.cols] = slab
 
-    def _to_rows(self, x):
+    def _to_rows(self, xs):
+        """Column slabs of several vectors -> whole rows of each, in ONE exchange."""
         g = self.comm.world
         if g == 1:
-            return x
-        y = self.comm.all_to_all(x.view(g, self.rows, self.cols))          # [source][rows][cols]
-        return y.permute(1, 0, 2).reshape(self.rows, self.S)
+            return list(xs)
+        import torch
+        send = torch.stack([x.view(g, self.rows, self.cols) for x in xs], dim=1)   # [dest][vector][rows][cols]
+        recv = self.comm.all_to_all(send)                                           # [source][vector][rows][cols]
+        return [recv[:, v].permute(1, 0, 2).reshape(self.rows, self.S) for v in range(len(xs))]
 
     def _to_slab(self, y):
         g = self.comm.world
@@ -332,7 +335,7 @@ class FourStepSharded:
         e, L, t, p = self.engine, self.log_len, self.log_t, self.p
         e.colpass(xa, L, t, self.col0, p, False, zero_hi)
         e.colpass(xb, L, t, self.col0, p, False, zero_hi)
-        ya, yb = self._to_rows(xa), self._to_rows(xb)
+        ya, yb = self._to_rows([xa, xb])
         yc = e.cyclic_multiply(ya.contiguous(), yb.contiguous(), p)
         xc = self._to_slab(yc).contiguous()
         e.colpass(xc, L, t, self.col0, p, True)

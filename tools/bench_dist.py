@@ -5,7 +5,7 @@
   --workload crt       4-prime CRT products of n = 2^17 u64 coefficients, primes dealt to ranks,
                        one all-to-all of residue slices per step (ntt_amd.distributed.CrtSharded)
   --workload batch     4096 independent products of length 2^16 / 2^17, batch dealt to ranks, no collective
-  --workload fourstep  one product of length 2^24..2^26 split by columns, three all-to-alls
+  --workload fourstep  one product of length 2^24..2^26 split by columns, two all-to-alls
                        (ntt_amd.distributed.FourStepSharded); with one rank it is also compared
                        with the single-GPU three-pass plan
 
