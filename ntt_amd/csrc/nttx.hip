@@ -101,7 +101,9 @@ static int decompose(int k, int lt[3]) {
     lt[1] = k - lt[0];
     return 2;
   }
+  // the 512-point row pass is the fused wave-per-row kernel: prefer it while both column passes stay >= 2^6
   int row = (k + 2) / 3; if (row > kMaxRowLog) row = kMaxRowLog;
+  if (row < 9 && k - 9 >= 2 * kMinColLog) row = 9;
   int rem = k - row;
   lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
   return 3;
