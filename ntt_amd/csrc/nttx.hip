@@ -91,6 +91,14 @@ struct Twist {
   ~Twist() { if (fwd) (void)hipFree(fwd); if (inv) (void)hipFree(inv); }
 };
 
+// Arithmetic class of the kernels for a modulus: the number of multiples of p known to fit an unsigned lane.
+static int arith_class(uint32_t p) { return (9ull * p < (1ull << 32)) ? 9 : (p < (1u << 30)) ? 4 : 2; }
+// The fused 512-point row kernel runs on signed lanes where 4p < 2^31 (NTTX_UNSIGNED=1: A/B measurements).
+static bool signed_rows(uint32_t p) {
+  static const bool unsigned_only = [] { const char *e = getenv("NTTX_UNSIGNED"); return e && atoi(e) != 0; }();
+  return p < (1u << 29) && !unsigned_only;
+}
+
 constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 
 static int decompose(int k, int lt[3]) {
@@ -222,7 +230,7 @@ static int get_plan(Context *cx, uint32_t p, int logL, bool conj, Plan **out) {
   if (!direct_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %u does not support a direct length-2^%d transform", p, logL);
   std::unique_ptr<Plan> pl(new Plan);
   pl->p = p; pl->logL = logL; pl->conj = conj;
-  pl->hclass = (9ull * p < (1ull << 32)) ? 9 : (p < (1u << 30)) ? 4 : 2;
+  pl->hclass = arith_class(p);
   pl->ctx = make_ctx(p);
   pl->npass = decompose(logL, pl->lt);
   const uint32_t g = find_nonresidue(p);
@@ -272,7 +280,10 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
   if (MODE == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
     const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
     static const int cap9 = env_int("NTTX_GRID_ROW", 8192);   // 4 rows per wave at batch 256: measured optimum
-    if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    if (H == 9 && signed_rows(A.ctx.p)) {
+      if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<1, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+      else hipLaunchKernelGGL((row_mul9_kernel<1, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    } else if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     else hipLaunchKernelGGL((row_mul9_kernel<H, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     HIPCHK(hipGetLastError());
     return 0;
@@ -602,7 +613,7 @@ static int get_slab(Context *cx, uint32_t p, int logL, int logT, long long col0,
   if (!direct_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %u does not support a direct length-2^%d transform", p, logL);
   std::unique_ptr<Slab> sl(new Slab);
   sl->ctx = make_ctx(p);
-  sl->hclass = (9ull * p < (1ull << 32)) ? 9 : (p < (1u << 30)) ? 4 : 2;
+  sl->hclass = arith_class(p);
   const uint32_t g = find_nonresidue(p);
   uint32_t wL = h_powmod(g, (uint64_t)(p - 1) >> logL, p);
   if (inverse) wL = h_powmod(wL, p - 2, p);
