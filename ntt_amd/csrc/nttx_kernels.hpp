@@ -136,7 +136,7 @@ struct Arith<1> {
     int64_t t, r;
     uint32_t m;
     asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"(x), "v"(w) : "vcc");
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"((uint32_t)t), "s"(pinv));
+    m = (uint32_t)t * pinv;
     asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(m), "s"(negp), "v"(t) : "vcc");
     return (uint32_t)((uint64_t)r >> 32);
   }
