@@ -35,6 +35,7 @@ MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per mu
 
 def cpu_baseline(n, p, reps=3):
     """Time the reference CPU program itself on this host (its own chrono line)."""
+    import numpy as np
     from oracle import pyoracle as po
     O = po.Oracle()
     cores = O.max_threads()
@@ -56,8 +57,39 @@ def cpu_baseline(n, p, reps=3):
         kind = "port"
         what = f"oracle/ntt_oracle.c restatement of main.cc, {len(ms)} multiplications, n={n}, p={p}, median"
     med = statistics.median(ms)
-    return {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "sample": what,
-            "ms_per_mult": med, "note": "the reference's NTT stage uses at most 4 threads (one per CRT prime, main.cc:306)"}
+    out = {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "sample": what,
+           "ms_per_mult": med, "note": "the reference's NTT stage uses at most 4 threads (one per CRT prime, main.cc:306)"}
+    # the reference's single-prime programs on the same workload (the CPU analogue of the GPU path):
+    # get_result_pthread (pthread_normal.cpp:361-413, 8 threads, Montgomery R = 2^30, conversions to and
+    # from Montgomery form included) and one ntt_compute_omp call (main.cc:185-209, Barrett, one thread)
+    if po.have_ref():
+        single = {}
+        a32 = np.asarray(cases[1][0], dtype=np.int32)
+        b32 = np.asarray(cases[1][1], dtype=np.int32)
+        for name, fn in (("pthread_normal.cpp get_result_pthread (8 threads)",
+                          lambda: po.RefMont("pthread_normal").poly_multiply(a32, b32, p)),
+                         ("monttry2.cpp get_result (8 threads per stage)",
+                          lambda: po.RefMont("monttry2").poly_multiply(a32, b32, p))):
+            ts = []
+            for _ in range(reps + 1):
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            single[name] = statistics.median(ts[1:])
+        L = 1 << (2 * n - 1).bit_length()
+        au = np.zeros(L, dtype=np.uint32)
+        bu = np.zeros(L, dtype=np.uint32)
+        au[:n] = a32
+        bu[:n] = b32
+        R = po.RefCRT("main")
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            R.ntt_compute(au, bu, p)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        single["main.cc ntt_compute_omp, one prime (1 thread)"] = statistics.median(ts)
+        out["single_prime_ms_per_mult"] = single
+    return out
 
 
 def main():
@@ -150,6 +182,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # two context figures, outside the timed region: what a plain device-to-device copy of the same
+    # buffers reaches on this GPU (read L*B words + write L*B words), and the latency of ONE resident product
+    copy_gbs = lat1_us = None
+    if rank == 0 and not args.no_events:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            c.copy_(a)
+        e0.record()
+        for _ in range(20):
+            c.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * 4 * L * B * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        for _ in range(50):
+            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P, 1, stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(200):
+            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P, 1, stream)
+        torch.cuda.synchronize()
+        lat1_us = (time.perf_counter() - t1) / 200 * 1e6
+
     if rank == 0:
         mults = world * B * args.steps
         value = mults / elapsed
@@ -192,9 +246,11 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no collective"},
             "ns_per_butterfly": elapsed / (mults / world) / butterflies * 1e9,
             "us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6,
+            "us_per_mult_batch_1": lat1_us,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms / dom_launches},
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms / dom_launches,
+                         "device_copy_GBs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs if copy_gbs else None},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()},
             "pipeline_model": {"bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "achieved_GBs_per_gpu": model_gbs,
                                "frac_of_peak": model_gbs / HBM_PEAK_GBS,

@@ -100,13 +100,25 @@ static bool signed_rows(uint32_t p) {
 }
 
 constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
+constexpr int kMinLongRow = 12, kMaxLongRow = 14;   // rows handled by one whole workgroup (longrow kernels)
+
+// NTTX_LONGROW (A/B measurements): bit 0 = long rows behind one column pass (lengths 2^21 .. 2^23), bit 1 = lengths 2^12 .. 2^14 in one pass
+static int longrow_mode() { static const int m = [] { const char *e = getenv("NTTX_LONGROW"); return e ? atoi(e) : 3; }(); return m; }
 
 static int decompose(int k, int lt[3]) {
   if (k <= kMaxRowLog) { lt[0] = k; return 1; }
-  if (k <= kMaxColLog + kMaxRowLog) {
+  if (k <= kMaxLongRow && (longrow_mode() & 2)) { lt[0] = k; return 1; }
+  if (k <= 9 + kMaxRowLog) {
     // 2^9-point column passes run on full 128-byte tiles; 2^10-point ones only on 64-byte tiles
-    lt[0] = (k - 9 <= kMaxRowLog) ? std::min(9, k / 2) : k / 2;
+    lt[0] = std::min(9, k / 2);
     lt[1] = k - lt[0];
+    return 2;
+  }
+  if (longrow_mode() & 1) {
+    // (a 2^10-point column pass around 2^14-point rows measured slower at 2^24 than three passes)
+    if (k <= 9 + kMaxLongRow) { lt[0] = 9; lt[1] = k - 9; return 2; }
+  } else if (k <= kMaxColLog + kMaxRowLog) {
+    lt[0] = k / 2; lt[1] = k - lt[0];
     return 2;
   }
   // the 512-point row pass is the fused wave-per-row kernel: prefer it while both column passes stay >= 2^6
@@ -285,6 +297,22 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
       else hipLaunchKernelGGL((row_mul9_kernel<1, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     } else if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
     else hipLaunchKernelGGL((row_mul9_kernel<H, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  // one row per workgroup: fused products from 2^10 points on (faster there than the tiled kernel
+  // below: one LDS buffer, outer rounds on registers), single transforms from 2^12 on
+  if (logT >= (MODE == ROW_MUL ? 10 : kMinLongRow) && logT <= kMaxLongRow) {
+    static const int capl = env_int("NTTX_GRID_LROW", 1 << 20);
+    const int grid = grid_for(A.nrows, capl);
+#define NTTX_LROW_CASE(K) case K: { \
+      constexpr int NT_ = LongRowLayout<K>::NTHR; \
+      if (MODE != ROW_MUL) hipLaunchKernelGGL((longrow_kernel<K, (MODE == ROW_MUL ? ROW_FWD : MODE), H>), dim3(grid), dim3(NT_), 0, st, A); \
+      else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 1>), dim3(grid), dim3(NT_), 0, st, A); \
+      else hipLaunchKernelGGL((longrow_mul_kernel<K, H>), dim3(grid), dim3(NT_), 0, st, A); \
+      break; }
+    switch (logT) { NTTX_LROW_CASE(10) NTTX_LROW_CASE(11) NTTX_LROW_CASE(12) NTTX_LROW_CASE(13) NTTX_LROW_CASE(14) default: break; }
+#undef NTTX_LROW_CASE
     HIPCHK(hipGetLastError());
     return 0;
   }

@@ -315,13 +315,15 @@ struct ColLayout {
 // the tile, for NV vectors that share twiddles (a and b of a product).
 // tw is the stage-major table: tw[h + j] = g^(j*T/(2h)), j < h, Montgomery form.
 // ------------------------------------------------------------------------------------
-template <class L, int R, int LOGD, bool INV, int H, int NV, bool ZHI, int KIN, int KOUT>
+// ROLLED: keep the loop over a thread's units rolled (kernels whose other live registers leave no
+// room for two units in flight).
+template <class L, int R, int LOGD, bool INV, int H, int NV, bool ZHI, int KIN, int KOUT, bool ROLLED = false>
 __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32_t *tw, const Arith<H> &M) {
   constexpr int D = 1 << LOGD;
   constexpr int LOG_UNITS = L::LOGT - R;  // log2(units per transform)
   constexpr int TOTAL = L::NT << LOG_UNITS;
   constexpr int NP = 1 << R;
-  for (int g = threadIdx.x; g < TOTAL; g += L::NTHR) {
+  auto unit = [&](int g) {
     int c, u;
     L::template split<LOG_UNITS>(g, c, u);
     const int lo = u & (D - 1), hi = u >> LOGD;
@@ -346,6 +348,12 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
 #pragma unroll
       for (int q = 0; q < NP; ++q) s[v][a0 + L::padj(q * D)] = x[q];
     }
+  };
+  if constexpr (ROLLED) {
+#pragma unroll 1
+    for (int g = threadIdx.x; g < TOTAL; g += L::NTHR) unit(g);
+  } else {
+    for (int g = threadIdx.x; g < TOTAL; g += L::NTHR) unit(g);
   }
 }
 
@@ -459,14 +467,14 @@ __device__ __forceinline__ void row_load(uint32_t *s, const uint32_t *in, long l
   constexpr int T = L::T;
   if constexpr (T >= 4) {
     constexpr int NV4 = L::NT * T / 4;
-    for (int v = threadIdx.x; v < NV4; v += WG) {
+    for (int v = threadIdx.x; v < NV4; v += L::NTHR) {
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       uint4 x = make_uint4(0, 0, 0, 0);
       if (row0 + c < nrows) x = *reinterpret_cast<const uint4 *>(in + (row0 + c) * T + j);
       *reinterpret_cast<uint4 *>(s + L::addr(c, j)) = x;
     }
   } else {
-    for (int v = threadIdx.x; v < L::NT * T; v += WG) {
+    for (int v = threadIdx.x; v < L::NT * T; v += L::NTHR) {
       const int c = v / T, j = v % T;
       s[L::addr(c, j)] = (row0 + c < nrows) ? in[(row0 + c) * T + j] : 0u;
     }
@@ -480,7 +488,7 @@ __device__ __forceinline__ void row_store(const uint32_t *s, uint32_t *out, long
   constexpr int T = L::T;
   if constexpr (T >= 4) {
     constexpr int NV4 = L::NT * T / 4;
-    for (int v = threadIdx.x; v < NV4; v += WG) {
+    for (int v = threadIdx.x; v < NV4; v += L::NTHR) {
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       if (row0 + c < nrows) {
         uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c, j));
@@ -489,7 +497,7 @@ __device__ __forceinline__ void row_store(const uint32_t *s, uint32_t *out, long
       }
     }
   } else {
-    for (int v = threadIdx.x; v < L::NT * T; v += WG) {
+    for (int v = threadIdx.x; v < L::NT * T; v += L::NTHR) {
       const int c = v / T, j = v % T;
       if (row0 + c < nrows) { uint32_t x = s[L::addr(c, j)]; out[(row0 + c) * T + j] = canon ? M.canon(V<Arith<H>::KI>{x}) : x; }
     }
@@ -640,6 +648,195 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
 #pragma unroll
     for (int q = 0; q < 8; ++q) po[lane + 64 * q] = CANON ? M.fix1(a[q]) : M.raw_out(a[q]);
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Long rows (2^10 .. 2^14 points): one row per workgroup of 128 .. 1024 threads, so lengths up to
+// 2^23 need only one column pass around the row pass (two trips through HBM per transform
+// instead of three) and lengths up to 2^14 a single pass.  The fused product sends a and then b through ONE LDS buffer: the outermost
+// forward round runs on registers straight from global memory, the distance-1 round of both
+// directions and the pointwise product run on registers too (a's values wait there while b uses
+// the buffer), and the outermost inverse round stores to global memory.  Stage twiddles of the
+// rounds at distance <= 64 come from an LDS copy of the first 512 table words, the outer rounds
+// read the table through the caches.
+// ------------------------------------------------------------------------------------
+template <int LOGT_>
+struct LongRowLayout {
+  static constexpr int LOGT = LOGT_;
+  static constexpr int T = 1 << LOGT;
+  static constexpr int NT = 1;
+  static constexpr int NTHR = (LOGT <= 11) ? (T / 8) : (LOGT <= 13) ? 512 : 1024;
+  static constexpr int TP = T + (T >> 6) * 8;
+  static constexpr int WORDS = TP;
+  __device__ static constexpr int padj(int j) { return j + ((j >> 6) << 3); }
+  __device__ static __forceinline__ int addr(int, int j) { return padj(j); }
+  template <int LOGU>
+  __device__ static __forceinline__ void split(int g, int &c, int &u) { c = 0; u = g; }
+};
+constexpr int LONG_TWL = 512;   // leading words of each stage table kept in LDS
+
+template <class L, int REM, int H>
+__device__ __forceinline__ void long_head(uint32_t *s, const uint32_t *twg, const uint32_t *twl, const Arith<H> &M) {
+  constexpr int KF = Arith<H>::KF;
+  if constexpr (REM > 3) {
+    uint32_t *const v[1] = {s};
+    ntt_round<L, 3, REM - 3, false, H, 1, false, KF, KF, true>(v, (8 << (REM - 3)) <= LONG_TWL ? twl : twg, M);
+    __syncthreads();
+    long_head<L, REM - 3, H>(s, twg, twl, M);
+  }
+}
+// inverse rounds between the distance-1 round and the outermost one (which stores to global memory)
+template <class L, int REM, int H>
+__device__ __forceinline__ void long_tail(uint32_t *s, const uint32_t *twg, const uint32_t *twl, const Arith<H> &M) {
+  constexpr int KI = Arith<H>::KI;
+  if constexpr (REM > 3) {
+    long_tail<L, REM - 3, H>(s, twg, twl, M);
+    if constexpr (REM < L::LOGT) {
+      uint32_t *const v[1] = {s};
+      ntt_round<L, 3, REM - 3, true, H, 1, false, KI, KI, true>(v, (8 << (REM - 3)) <= LONG_TWL ? twl : twg, M);
+      __syncthreads();
+    }
+  }
+}
+// distance-1 round on registers: r[u*NP + q] = point q of the thread's u-th unit
+template <class L, int RL, bool INV, int H, int KIN, int KOUT, int PT>
+__device__ __forceinline__ void long_edge(uint32_t *s, const uint32_t *tw, const Arith<H> &M, uint32_t (&r)[PT]) {
+  constexpr int NP = 1 << RL, NU = PT / NP;
+  static_assert((L::T >> RL) == NU * L::NTHR, "PT points per thread");
+  uint32_t w[NP];
+  w[0] = 0;
+#pragma unroll
+  for (int m = 1; m < NP; ++m) w[m] = tw[m];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int a0 = L::padj((threadIdx.x + u * L::NTHR) << RL);
+    uint32_t x[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) x[q] = INV ? r[u * NP + q] : s[a0 + q];
+    if constexpr (RL == 3) { if constexpr (!INV) r8_dif<H, true, false, KIN, KOUT>(x, w, M); else r8_dit<H, true, KIN, KOUT>(x, w, M); }
+    else if constexpr (RL == 2) r4_unit<H, true, INV, KIN, KOUT>(x, w, M);
+    else r2_unit<H, true, INV, KIN, KOUT>(x, w, M);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { if (INV) s[a0 + q] = x[q]; else r[u * NP + q] = x[q]; }
+  }
+}
+
+template <int LOGT, int H>
+__global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(RowArgs A) {
+  using L = LongRowLayout<LOGT>;
+  constexpr int T = L::T, NTHR = L::NTHR;
+  constexpr int RL = (LOGT - 1) % 3 + 1;          // stages of the distance-1 round
+  constexpr int D1 = T / 8, LOGD1 = LOGT - 3;     // outermost round
+  constexpr int NU = D1 / NTHR;                   // outermost-round units per thread
+  constexpr int PT = T / NTHR;                    // points per thread
+  constexpr int KF = Arith<H>::KF, KI = Arith<H>::KI, KP = Arith<H>::KP, KM = Arith<H>::KM, KANY = Arith<H>::KANY;
+  static_assert(NU >= 1 && LOGD1 >= 6, "row too short for this kernel");
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L::WORDS + 2 * LONG_TWL];
+  uint32_t *sa = lds, *twf = lds + L::WORDS, *twi = twf + LONG_TWL;
+  const Arith<H> M(A.ctx);
+  for (int i = threadIdx.x; i < LONG_TWL; i += NTHR) { twf[i] = A.tw_fwd[i]; twi[i] = A.tw_inv[i]; }
+
+  for (long long row = blockIdx.x; row < A.nrows; row += gridDim.x) {
+    const uint32_t *pa = A.in0 + row * T, *pb = A.in1 + row * T;
+    // b's outermost-round points are fetched together with a's where the registers allow it; longer
+    // rows fetch each unit right before its butterflies (a row takes tens of microseconds, so the
+    // exposed latency is small next to what spilled registers would cost)
+    constexpr bool EARLY_B = (NU == 1 && NTHR == 512);
+    uint32_t xb[8], w1[8];
+    uint32_t ra[PT], rb[PT];
+    w1[0] = 0;
+    if (EARLY_B) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xb[q] = pb[threadIdx.x + q * D1];
+    }
+    __syncthreads();                               // previous row (and the twiddle copy) settled
+    // ---- a: forward
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+      const int g = threadIdx.x + u * NTHR;
+      uint32_t xa[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[q] = pa[g + q * D1];
+#pragma unroll
+      for (int m = 1; m < 8; ++m) w1[m] = A.tw_fwd[g + m * D1];
+      r8_dif<H, false, false, Arith<H>::KROW, KF>(xa, w1, M);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sa[L::padj(g + q * D1)] = xa[q];
+    }
+    __syncthreads();
+    long_head<L, LOGD1, H>(sa, A.tw_fwd, twf, M);
+    long_edge<L, RL, false, H, KF, KP, PT>(sa, twf, M, ra);
+    __syncthreads();
+    // ---- b: forward
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+      const int g = threadIdx.x + u * NTHR;
+      if (!EARLY_B) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xb[q] = pb[g + q * D1];
+        if (NU > 1) {
+#pragma unroll
+          for (int m = 1; m < 8; ++m) w1[m] = A.tw_fwd[g + m * D1];
+        }
+      }
+      r8_dif<H, false, false, Arith<H>::KROW, KF>(xb, w1, M);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sa[L::padj(g + q * D1)] = xb[q];
+    }
+    __syncthreads();
+    long_head<L, LOGD1, H>(sa, A.tw_fwd, twf, M);
+    long_edge<L, RL, false, H, KF, KP, PT>(sa, twf, M, rb);
+    // ---- pointwise product, inverse
+    if (A.scale) {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) ra[k] = M.mul(M.mul2(V<KP>{ra[k]}, V<KP>{rb[k]}), A.scale).v;
+    } else {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) ra[k] = M.mul2(V<KP>{ra[k]}, V<KP>{rb[k]}).v;
+    }
+    long_edge<L, RL, true, H, KM, KI, PT>(sa, twi, M, ra);   // each thread rewrites only the points it read
+    __syncthreads();
+    long_tail<L, LOGT, H>(sa, A.tw_inv, twi, M);
+    uint32_t *po = A.out + row * T;
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+      const int g = threadIdx.x + u * NTHR;
+      uint32_t x[8], w[8];
+      w[0] = 0;
+#pragma unroll
+      for (int m = 1; m < 8; ++m) w[m] = A.tw_inv[g + m * D1];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = sa[L::padj(g + q * D1)];
+      if (A.canon_out) {
+        r8_dit<H, false, KI, 1>(x, w, M);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) po[g + q * D1] = M.fix1(x[q]);
+      } else {
+        r8_dit<H, false, KI, KANY>(x, w, M);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) po[g + q * D1] = M.raw_out(x[q]);
+      }
+    }
+  }
+}
+
+// single transforms on long rows (the transform API): every round through LDS
+template <int LOGT, int MODE, int H>
+__global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_kernel(RowArgs A) {
+  using L = LongRowLayout<LOGT>;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L::WORDS];
+  const Arith<H> M(A.ctx);
+  constexpr int KF = Arith<H>::KF, KI = Arith<H>::KI;
+  for (long long row = blockIdx.x; row < A.nrows; row += gridDim.x) {
+    __syncthreads();
+    row_load<L>(lds, A.in0, row, A.nrows);
+    __syncthreads();
+    uint32_t *const v[1] = {lds};
+    if (MODE == ROW_FWD) dif_rounds<L, LOGT, H, 1, false, KF, KI>(v, A.tw_fwd, M);
+    else dit_rounds<L, LOGT, H, 1, KI, KI>(v, A.tw_inv, M);
+    __syncthreads();
+    row_store<L, H>(lds, A.out, row, A.nrows, M, A.canon_out != 0);
   }
 }
 

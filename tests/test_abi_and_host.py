@@ -69,10 +69,14 @@ def test_plan_decomposition():
     import ntt_amd
     assert ntt_amd.plan_info(2) == [1]
     assert ntt_amd.plan_info(1 << 11) == [11]
-    assert ntt_amd.plan_info(1 << 12) == [6, 6]
+    assert ntt_amd.plan_info(1 << 12) == [12]               # one workgroup per row up to 2^14 points
+    assert ntt_amd.plan_info(1 << 14) == [14]
+    assert ntt_amd.plan_info(1 << 15) == [7, 8]
     assert ntt_amd.plan_info(1 << 18) == [9, 9]
-    assert ntt_amd.plan_info(1 << 21) == [10, 11]
-    for k in range(22, 31):
+    assert ntt_amd.plan_info(1 << 20) == [9, 11]
+    assert ntt_amd.plan_info(1 << 21) == [9, 12]
+    assert ntt_amd.plan_info(1 << 23) == [9, 14]
+    for k in range(24, 31):
         lt = ntt_amd.plan_info(1 << k)
         assert len(lt) == 3 and sum(lt) == k and all(6 <= x <= 10 for x in lt[:2]) and lt[2] <= 11
     with pytest.raises(ntt_amd.NttxError):

@@ -135,13 +135,81 @@ def _horner(v, x, p):
 
 
 def test_three_pass_length(nttx, oracle):
-    """2^22-point product (three passes) against the oracle, plus a point-evaluation check."""
-    p, n = 469762049, 1 << 21
-    assert len(nttx.plan_info(1 << 22)) == 3
-    a, b = rand(oracle, n, 41, p), rand(oracle, n, 42, p)
-    got = nttx.poly_multiply(a, b, n, p, dtype=np.uint64)
-    want = oracle.poly_multiply_crt(a, b, p)
-    assert np.array_equal(got, want)
+    """2^24-point cyclic product (three passes): a sparse factor makes the expected product a handful of
+    shifted copies of the dense one, so no CPU transform of that size is needed."""
+    p, L = 469762049, 1 << 24
+    assert len(nttx.plan_info(L)) == 3
+    a = rand(oracle, L, 41, p).astype(np.uint32)
+    b = np.zeros(L, np.uint32)
+    terms = {0: 3, 1: p - 1, 12345: 77, L // 2 + 5: 123456789, L - 1: 2}
+    for k, v in terms.items():
+        b[k] = v
+    want = np.zeros(L, np.uint64)
+    for k, v in terms.items():
+        want = (want + np.roll(a, k).astype(np.uint64) * np.uint64(v)) % np.uint64(p)
+    assert np.array_equal(nttx.cyclic_multiply(a, b, p), want.astype(np.uint32))
+    assert np.array_equal(nttx.cyclic_multiply(b, a, p), want.astype(np.uint32))
+
+
+_THREE_PASS_22 = """
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import ntt_amd
+from oracle import pyoracle
+O = pyoracle.Oracle()
+ntt_amd.init(0)
+p, n = 469762049, 1 << 21
+assert len(ntt_amd.plan_info(1 << 22)) == 3, ntt_amd.plan_info(1 << 22)
+a, b = O.fill_random(n, 41, p), O.fill_random(n, 42, p)
+assert np.array_equal(ntt_amd.poly_multiply(a, b, n, p, dtype=np.uint64), O.poly_multiply_crt(a, b, p))
+ntt_amd.shutdown()
+print("three-pass ok")
+"""
+
+
+def test_three_pass_plan_at_2_22(oracle):
+    """The three-pass plan on a length the default plan covers in two passes (long rows switched off in a
+    child process), against the oracle's product."""
+    import subprocess
+    import sys
+    root = os.path.dirname(GOLD[:-len("/golden")])
+    env = dict(os.environ, NTTX_LONGROW="0")
+    r = subprocess.run([sys.executable, "-c", _THREE_PASS_22.format(root=root)], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "three-pass ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("p", (469762049, 998244353, 1224736769))
+def test_long_row_single_pass(nttx, oracle, p):
+    """Lengths 2^12 .. 2^14 run as ONE pass (a whole workgroup per row); all three modulus classes and
+    the signed-lane class, batches that do and do not fill the grid, against ntt_compute_omp."""
+    for logn, batch in ((12, 5), (13, 3), (14, 2)):
+        n = 1 << logn
+        assert nttx.plan_info(n) == [logn]
+        a = rand(oracle, n * batch, 300 + logn, p).astype(np.uint32).reshape(batch, n)
+        b = rand(oracle, n * batch, 400 + logn, p).astype(np.uint32).reshape(batch, n)
+        got = _dev_cyclic(nttx, a, b, p)
+        for i in range(batch):
+            assert np.array_equal(got[i], oracle.ntt_compute(a[i], b[i], p)), (p, logn, i)
+
+
+def _dev_cyclic(nttx, a, b, p):
+    import torch
+    da, db = torch.from_numpy(a.view(np.int32)).cuda(), torch.from_numpy(b.view(np.int32)).cuda()
+    dc = torch.empty_like(da)
+    nttx.dev_cyclic_multiply_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), a.shape[1], p, a.shape[0],
+                                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return dc.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("p,logn", [(469762049, 21), (469762049, 22), (469762049, 23), (998244353, 22), (1224736769, 23)])
+def test_long_row_two_pass(nttx, oracle, p, logn):
+    """One column pass around long rows (2^12 .. 2^14 points): cyclic products of length 2^21 .. 2^23
+    against ntt_compute_omp."""
+    n = 1 << logn
+    assert len(nttx.plan_info(n)) == 2
+    a, b = rand(oracle, n, 500 + logn, p).astype(np.uint32), rand(oracle, n, 600 + logn, p).astype(np.uint32)
+    assert np.array_equal(nttx.cyclic_multiply(a, b, p), oracle.ntt_compute(a, b, p))
 
 
 def test_inputs_not_reduced(nttx, oracle):

@@ -103,6 +103,13 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         dt = timed(lambda: ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, nb, st),
                    args.steps, args.warmup, torch, dist, dev)
+        ntt_amd.profile_reset()
+        ntt_amd.profile_enable(True)                # per-kernel HIP-event times of a few more steps
+        for _ in range(10):
+            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, nb, st)
+        torch.cuda.synchronize()
+        ntt_amd.profile_enable(False)
+        out["kernels_ms_per_step"] = {k: round(v[0] / 10, 4) for k, v in ntt_amd.profile_read().items() if v[1] > 0}
         out.update(batch=B, log2_len=logL, poly_mults_per_s=B * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
                    us_per_mult_per_gpu=dt / args.steps / nb * 1e6, passes=ntt_amd.plan_info(L),
                    model_GBs_per_gpu=52 * L * nb * args.steps / dt / 1e9)
