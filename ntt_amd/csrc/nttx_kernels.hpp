@@ -117,28 +117,38 @@ struct Arith {
   __device__ __forceinline__ uint32_t raw_out(uint32_t v) const { return v; }
 };
 
-// Signed class (H = 1), used by the fused 512-point row kernel for p < 2^29, where 4p fits a signed 32-bit lane: V<K> holds an int32 of
+// Signed classes (H = 1 and H = 0), used by the fused row kernels for p < 2^29, where 4p fits a signed 32-bit lane: V<K> holds an int32 of
 // magnitude below K*p (K <= 4).  Sums and differences need no offset, a signed REDC returns a value in
 // (-p, p), and any value is brought back into that range by one multiplication by 1 (three
 // instructions, the price of one and a half conditional subtractions) instead of a chain of them.
 // Counted over a radix-8 unit this is 12-18 % fewer instructions than the unsigned class with 9p < 2^32.
-template <>
-struct Arith<1> {
+// ASM: the two multiply-adds of the REDC as inline assembly (the 512-point kernel, where the fixed
+// pairing is 1 % faster) or left to the compiler's scheduler (the long-row kernels, where inline
+// assembly costs hazard no-ops the scheduler cannot fill: 4-11 % slower).
+template <bool ASM>
+struct SignedArith {
   static constexpr int HS = 4;        // largest admissible bound
   static constexpr int KM = 1, KF = 1, KI = 4, KP = 2, KANY = 4;
   uint32_t p, pinv, one;
   int32_t negp;
-  __device__ __forceinline__ Arith(const PrimeCtx &c) : p(c.p), pinv(0u - c.npinv), one(c.one), negp(-(int32_t)c.p) {}
+  __device__ __forceinline__ SignedArith(const PrimeCtx &c) : p(c.p), pinv(0u - c.npinv), one(c.one), negp(-(int32_t)c.p) {}
   // x*w*2^-32 mod p in (-p, p) for |x| < 2^31, |w| < p: t - m p has a zero low word and |t - m p| < 2^32 p
-  // Written as the three instructions it is (left to the compiler, part of the signed 64-bit products
-  // come out as unsigned multiplies plus sign fix-ups).
+  // (three instructions: v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32; the subtraction is folded into the
+  // second multiply-add by multiplying with -p)
   __device__ __forceinline__ uint32_t sredc(uint32_t x, uint32_t w) const {
-    int64_t t, r;
-    uint32_t m;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"(x), "v"(w) : "vcc");
-    m = (uint32_t)t * pinv;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(m), "s"(negp), "v"(t) : "vcc");
-    return (uint32_t)((uint64_t)r >> 32);
+    if constexpr (ASM) {
+      int64_t t, r;
+      uint32_t m;
+      asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"(x), "v"(w) : "vcc");
+      m = (uint32_t)t * pinv;
+      asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(m), "s"(negp), "v"(t) : "vcc");
+      return (uint32_t)((uint64_t)r >> 32);
+    } else {
+      const int64_t t = (int64_t)(int32_t)x * (int64_t)(int32_t)w;
+      const uint32_t m = (uint32_t)t * pinv;
+      const int64_t r = (int64_t)(int32_t)m * (int64_t)negp + t;
+      return (uint32_t)((uint64_t)r >> 32);
+    }
   }
   template <int K>
   __device__ __forceinline__ V<1> mul(V<K> x, uint32_t w) const { return V<1>{sredc(x.v, w)}; }
@@ -181,6 +191,10 @@ struct Arith<1> {
   static constexpr int KROW = 2;
   __device__ __forceinline__ uint32_t raw_out(uint32_t v) const { return v + 4u * p; }
 };
+template <>
+struct Arith<1> : SignedArith<true> { __device__ __forceinline__ Arith(const PrimeCtx &c) : SignedArith<true>(c) {} };
+template <>
+struct Arith<0> : SignedArith<false> { __device__ __forceinline__ Arith(const PrimeCtx &c) : SignedArith<false>(c) {} };
 
 // ------------------------------------------------------------------------------------
 // Radix-8 / 4 / 2 units on registers: stages at point distances 4D, 2D, D.
