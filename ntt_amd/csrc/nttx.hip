@@ -502,10 +502,12 @@ static const CrtConst &crt_const() {
   return cc;
 }
 
-static int fill_crt_args(CrtArgs &A, uint64_t p) {
+// constants for recombining residues modulo kCrtPrimes[sel[0..ns-1]] (ascending)
+static int fill_crt_args(CrtArgs &A, uint64_t p, const int *sel, int ns) {
   const CrtConst &cc = crt_const();
-  for (int k = 0; k < 4; ++k) { A.ctx[k] = cc.ctx[k]; for (int j = 0; j < 4; ++j) A.inv[k][j] = cc.inv[k][j]; }
-  A.nmod = 4;
+  for (int k = 0; k < ns; ++k) { A.ctx[k] = cc.ctx[sel[k]]; for (int j = 0; j < ns; ++j) A.inv[k][j] = cc.inv[sel[k]][sel[j]]; }
+  for (int k = ns; k < 4; ++k) A.ctx[k] = cc.ctx[3];   // unused slots: any valid modulus
+  A.nmod = ns;
   if (p < 2 || p >= (1ull << 63)) return fail(NTTX_EINVAL, "modulus out of range");
   int e = 0; uint64_t q = p;
   while ((q & 1) == 0) { q >>= 1; ++e; }             // p = 2^e * q, q odd
@@ -514,16 +516,18 @@ static int fill_crt_args(CrtArgs &A, uint64_t p) {
   A.qinv = 0ull - A.pctx.npinv;                      // q^{-1} mod 2^64
   if (q > 1) {
     uint64_t c = (uint64_t)((((unsigned __int128)1) << 64) % q);     // 2^64 mod q
-    for (int k = 0; k < 4; ++k) { A.cR[k] = c; c = h_mulmod64(c, kCrtPrimes[k] % q, q); }
+    for (int k = 0; k < ns; ++k) { A.cR[k] = c; c = h_mulmod64(c, kCrtPrimes[sel[k]] % q, q); }
   }
   return 0;
 }
+static int fill_crt_args(CrtArgs &A, uint64_t p) { const int all[4] = {0, 1, 2, 3}; return fill_crt_args(A, p, all, 4); }
 
-// exactness bound of the 4-prime path: every coefficient of the integer product, at most
-// n*(amax)*(bmax) with amax,bmax <= p-1, must stay below M (cf. "sum % M" main.cc:330)
-static bool crt_bound_ok(uint64_t p, int n) {
-  const CrtConst &cc = crt_const();
-  const long double lim = (long double)cc.M;
+// exactness bound of the CRT path: every coefficient of the integer product, at most
+// n*(amax)*(bmax) with amax,bmax <= p-1, must stay below the product of the moduli used
+// (cf. "sum % M" main.cc:330).  first = 0: all four primes; first = 1: the three largest.
+static bool crt_bound_ok(uint64_t p, int n, int first = 0) {
+  long double lim = 1;
+  for (int k = first; k < 4; ++k) lim *= (long double)kCrtPrimes[k];
   const long double need = (long double)n * (long double)(p - 1) * (long double)(p - 1);
   return need < lim * 0.999L;
 }
@@ -534,23 +538,30 @@ static int log2_ceil_len(int n) {  // main.cc:278-279: smallest power of two >= 
   return k;
 }
 
-// d_ab[b][0..2n-2] from u64 device inputs through the 4-prime path
+// d_ab[b][0..2n-2] from u64 device inputs through the CRT path: the reference's four primes
+// (main.cc:245-248), or only the three largest where n*(p-1)^2 stays below their product (every
+// modulus below 2^36 at n = 2^17): a quarter of the transforms less, the same coefficients
 static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_ab, int n, uint64_t p,
                             int batch, hipStream_t st) {
   const int logL = log2_ceil_len(n);
   if (logL > 21) return fail(NTTX_ERANGE, "length 2^%d exceeds the CRT prime set (2^21)", logL);
   if (!crt_bound_ok(p, n)) return fail(NTTX_ERANGE, "n*(p-1)^2 exceeds the product of the CRT primes");
+  static const bool four_only = [] { const char *e = getenv("NTTX_CRT_FOUR"); return e && atoi(e) != 0; }();
+  const int first = (!four_only && crt_bound_ok(p, n, 1)) ? 1 : 0;
+  const int ns = 4 - first;
+  int sel[4];
+  for (int k = 0; k < ns; ++k) sel[k] = first + k;
   const long long len = 1ll << logL;
   const size_t vec = (size_t)batch * len * 4;
-  if (int rc = cx->pa.ensure(4 * vec)) return rc;
-  if (int rc = cx->pb.ensure(4 * vec)) return rc;
-  if (int rc = cx->pc.ensure(4 * vec)) return rc;
+  if (int rc = cx->pa.ensure(ns * vec)) return rc;
+  if (int rc = cx->pb.ensure(ns * vec)) return rc;
+  if (int rc = cx->pc.ensure(ns * vec)) return rc;
   Plan *pl[4];
-  for (int k = 0; k < 4; ++k) if (int rc = get_plan(cx, kCrtPrimes[k], logL, false, &pl[k])) return rc;
+  for (int k = 0; k < ns; ++k) if (int rc = get_plan(cx, kCrtPrimes[sel[k]], logL, false, &pl[k])) return rc;
   {
-    SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = 4; S.n = n; S.len = (int)len;
+    SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
     S.zfill = pl[0]->npass == 1 ? (int)len : n;   // multi-pass products never read the padding
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < ns; ++k) {
       S.dst[0][k] = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
       S.dst[1][k] = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
       S.ctx[k] = pl[k]->ctx;
@@ -562,8 +573,8 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
     HIPCHK(hipGetLastError());
   }
   CrtArgs A{};
-  if (int rc = fill_crt_args(A, p)) return rc;
-  for (int k = 0; k < 4; ++k) {
+  if (int rc = fill_crt_args(A, p, sel, ns)) return rc;
+  for (int k = 0; k < ns; ++k) {
     const uint32_t *a = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
     const uint32_t *b = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
     uint32_t *c = cx->pc.as<uint32_t>() + (size_t)k * batch * len;

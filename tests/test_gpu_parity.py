@@ -83,6 +83,21 @@ def test_crt_path_small(nttx, oracle, p):
             assert np.array_equal(want, oracle.poly_multiply_naive_u64(a, b, p))
 
 
+def test_crt_three_prime_bound(nttx, oracle):
+    """The CRT route drops the smallest prime where n*(p-1)^2 stays below the product of the other three.
+    Worst-case inputs (every coefficient p-1, so the middle coefficient of the integer product reaches
+    n*(p-1)^2) on both sides of that bound, plus random inputs, against the four-prime oracle."""
+    m3 = 998244353 * 1004535809 * 1224736769
+    for n in (1000, 4096, 65536):
+        edge = int((m3 * 0.999 / n) ** 0.5)
+        for p in (edge - 12345, edge + 12345, 2147483647, (1 << 36) - 5):
+            assert nttx.path_for(p, n) == nttx.PATH_CRT4
+            worst = np.full(n, p - 1, dtype=np.uint64)
+            assert np.array_equal(nttx.poly_multiply(worst, worst, n, p, dtype=np.uint64), oracle.poly_multiply_crt(worst, worst, p)), (n, p)
+            a, b = rand(oracle, n, 11 + n, p), rand(oracle, n, 12 + n, p)
+            assert np.array_equal(nttx.poly_multiply(a, b, n, p, dtype=np.uint64), oracle.poly_multiply_crt(a, b, p)), (n, p)
+
+
 @pytest.mark.parametrize("p", (2, 3, 4, 6, 12, 17, 65536, 65537, 1 << 31, 3 << 40, 1 << 62, 1000000007, (1 << 61) - 1))
 def test_any_modulus_like_main_cc(nttx, oracle, p):
     """main.cc reduces the exact integer product modulo whatever p it is given (main.cc:334-336):

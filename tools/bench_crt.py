@@ -1,10 +1,11 @@
-"""Throughput of the 4-prime CRT path on resident u64 inputs:
-n = 2^17 coefficients, p = 1337006139375617 (harness id 4), batch of independent products."""
+"""Throughput of the CRT path on resident u64 inputs: n = 2^17 coefficients, p = 1337006139375617
+(harness id 4; four primes) or the modulus in $P (moduli below 2^36 take three primes), batch of
+independent products; for the default modulus also the direct 64-bit-lane path."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ntt_amd
 from oracle import pyoracle as po
-P, n, B = 1337006139375617, 1 << 17, int(os.environ.get("B", 32))
+P, n, B = int(os.environ.get("P", 1337006139375617)), 1 << 17, int(os.environ.get("B", 32))
 ntt_amd.init(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(7)
@@ -27,9 +28,12 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t0
 ntt_amd.profile_enable(False)
 prof = {k: round(v[0] / K, 4) for k, v in ntt_amd.profile_read().items() if v[1]}
 L = 2 * n
-print(json.dumps({"workload": "4-prime CRT, n=2^17, p=1337006139375617", "batch": B, "poly_mults_per_s": B * K / dt,
+print(json.dumps({"workload": "CRT route, n=2^17, p=%d" % P, "batch": B, "poly_mults_per_s": B * K / dt,
                   "us_per_mult": dt / (B * K) * 1e6, "ns_per_butterfly": dt / (B * K) / (4 * 3 * (L // 2) * 18) * 1e9,
                   "kernels_ms_per_step": prof, "model_bytes_280L": 280 * L, "model_GBs": 280 * L * B * K / dt / 1e9}))
+if ntt_amd.path_for(P, n) != ntt_amd.PATH_DIRECT64:
+    ntt_amd.shutdown()
+    sys.exit(0)
 
 # the same products on the 64-bit-lane direct path (zero-padded [B][2n] arrays, as the 32-bit device call takes)
 pa = torch.zeros((B, L), dtype=torch.int64, device=dev); pa[:, :n] = a
