@@ -83,15 +83,24 @@ def test_crt_path_small(nttx, oracle, p):
             assert np.array_equal(want, oracle.poly_multiply_naive_u64(a, b, p))
 
 
-def test_crt_three_prime_bound(nttx, oracle):
-    """The CRT route drops the smallest prime where n*(p-1)^2 stays below the product of the other three.
-    Worst-case inputs (every coefficient p-1, so the middle coefficient of the integer product reaches
-    n*(p-1)^2) on both sides of that bound, plus random inputs, against the four-prime oracle."""
-    m3 = 998244353 * 1004535809 * 1224736769
+def test_crt_fewer_primes_bound(nttx, oracle):
+    """The CRT route uses only the largest three, two or one of the four primes where n*(p-1)^2 stays
+    below their product.  Worst-case inputs (every coefficient p-1, so the middle coefficient of the
+    integer product reaches n*(p-1)^2) on both sides of each bound, plus random inputs, against the
+    four-prime oracle."""
+    primes = (998244353, 1004535809, 1224736769)
     for n in (1000, 4096, 65536):
-        edge = int((m3 * 0.999 / n) ** 0.5)
-        for p in (edge - 12345, edge + 12345, 2147483647, (1 << 36) - 5):
-            assert nttx.path_for(p, n) == nttx.PATH_CRT4
+        moduli = [2147483647, (1 << 36) - 5, 65537, 97, 12345678]
+        for first in range(3):
+            prod = 1
+            for m in primes[first:]:
+                prod *= m
+            edge = int((prod * 0.999 / n) ** 0.5)
+            moduli += [edge - edge // 100000 - 3, edge + edge // 100000 + 3]
+        for p in moduli:
+            if nttx.path_for(p, n) != nttx.PATH_CRT4:
+                p += 1                      # an NTT-friendly prime would take a direct route: step off it
+            assert nttx.path_for(p, n) == nttx.PATH_CRT4, (p, n)
             worst = np.full(n, p - 1, dtype=np.uint64)
             assert np.array_equal(nttx.poly_multiply(worst, worst, n, p, dtype=np.uint64), oracle.poly_multiply_crt(worst, worst, p)), (n, p)
             a, b = rand(oracle, n, 11 + n, p), rand(oracle, n, 12 + n, p)
