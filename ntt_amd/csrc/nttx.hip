@@ -287,16 +287,23 @@ static int get_plan(Context *cx, uint32_t p, int logL, bool conj, Plan **out) {
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static int grid_for(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
 
-template <int MODE, int H>
+template <int MODE, int H, bool TWIST = false>
 static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
+  if constexpr (MODE == ROW_MUL && !TWIST) {
+    if (A.psi_in) return launch_row_t<MODE, H, true>(logT, A, st);   // negacyclic product: psi factors fused
+  }
   if (MODE == ROW_MUL && logT == 9) {   // wave-per-row fused kernel
     const long long wgs = (A.nrows + (WG / 64) - 1) / (WG / 64);
     static const int cap9 = env_int("NTTX_GRID_ROW", 8192);   // 4 rows per wave at batch 256: measured optimum
-    if (H == 9 && signed_rows(A.ctx.p)) {
-      if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<1, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
-      else hipLaunchKernelGGL((row_mul9_kernel<1, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
-    } else if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
-    else hipLaunchKernelGGL((row_mul9_kernel<H, false>), dim3(grid_for(wgs, cap9)), dim3(WG), 0, st, A);
+    const dim3 grid(grid_for(wgs, cap9));
+    if constexpr (TWIST) {
+      if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((row_mul9_kernel<1, true, true>), grid, dim3(WG), 0, st, A);
+      else hipLaunchKernelGGL((row_mul9_kernel<H, true, true>), grid, dim3(WG), 0, st, A);
+    } else if (H == 9 && signed_rows(A.ctx.p)) {
+      if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<1, true>), grid, dim3(WG), 0, st, A);
+      else hipLaunchKernelGGL((row_mul9_kernel<1, false>), grid, dim3(WG), 0, st, A);
+    } else if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), grid, dim3(WG), 0, st, A);
+    else hipLaunchKernelGGL((row_mul9_kernel<H, false>), grid, dim3(WG), 0, st, A);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -308,8 +315,8 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
 #define NTTX_LROW_CASE(K) case K: { \
       constexpr int NT_ = LongRowLayout<K>::NTHR; \
       if (MODE != ROW_MUL) hipLaunchKernelGGL((longrow_kernel<K, (MODE == ROW_MUL ? ROW_FWD : MODE), H>), dim3(grid), dim3(NT_), 0, st, A); \
-      else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 0>), dim3(grid), dim3(NT_), 0, st, A); \
-      else hipLaunchKernelGGL((longrow_mul_kernel<K, H>), dim3(grid), dim3(NT_), 0, st, A); \
+      else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 0, TWIST>), dim3(grid), dim3(NT_), 0, st, A); \
+      else hipLaunchKernelGGL((longrow_mul_kernel<K, H, TWIST>), dim3(grid), dim3(NT_), 0, st, A); \
       break; }
     switch (logT) { NTTX_LROW_CASE(10) NTTX_LROW_CASE(11) NTTX_LROW_CASE(12) NTTX_LROW_CASE(13) NTTX_LROW_CASE(14) default: break; }
 #undef NTTX_LROW_CASE
@@ -319,7 +326,7 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
 #define NTTX_ROW_CASE(K) case K: { \
     using Lyt = RowLayout<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    hipLaunchKernelGGL((row_kernel<K, MODE, H>), dim3(grid_for(tiles, capg)), dim3(WG), 0, st, A); break; }
+    hipLaunchKernelGGL((row_kernel<K, MODE, H, TWIST>), dim3(grid_for(tiles, capg)), dim3(WG), 0, st, A); break; }
   static const int capg = env_int("NTTX_GRID_ROWG", 8192);
   switch (logT) {
     NTTX_ROW_CASE(1) NTTX_ROW_CASE(2) NTTX_ROW_CASE(3) NTTX_ROW_CASE(4) NTTX_ROW_CASE(5) NTTX_ROW_CASE(6)
@@ -356,6 +363,19 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int grid = g16 <= tiles ? g16 : grid_for(tiles, cap);
 #define NTTX_COL_CASE(K, LC, NT) \
     hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, FS2>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+  if constexpr (!FS2 && !ZHI) {
+    if (A.psi) {   // outermost pass of a negacyclic product (full 128-byte tiles only: the caller checks)
+#define NTTX_COLT_CASE(K, NT) \
+      hipLaunchKernelGGL((col_kernel<K, INV, H, 5, NT, false, false, true>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+      switch (wide ? logT : 0) {
+        case 6: NTTX_COLT_CASE(6, 256)  case 7: NTTX_COLT_CASE(7, 256)  case 8: NTTX_COLT_CASE(8, 256)  case 9: NTTX_COLT_CASE(9, 1024)
+        default: return fail(NTTX_ERANGE, "twisted column pass of 2^%d points unsupported", logT);
+      }
+#undef NTTX_COLT_CASE
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+  }
   if constexpr (FS2) {
     switch (logT * 2 + wide) {
       case 15: NTTX_COL_CASE(7, 5, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
@@ -428,12 +448,17 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 // c = cyclic product of a and b, all [batch][2^logL] u32 on the device
 // nvalid > 0: only the first nvalid words of every input vector are read, the rest counts as zero
 // (the zero padding of a linear product, main.cc:280-281); needs nvalid <= len/2 to take effect.
+// psi_in / psi_out (one- and two-pass plans only): the product becomes the negacyclic one, a and b multiplied by
+// psi_in[i] as the first pass reads them and c by psi_out[i] as the last pass writes it
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
-                               hipStream_t st, long long nvalid = 0) {
+                               hipStream_t st, long long nvalid = 0, const uint32_t *psi_in = nullptr,
+                               const uint32_t *psi_out = nullptr) {
   const long long len = 1ll << pl->logL;
+  if (psi_in && pl->npass > 2) return fail(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
   if (pl->npass == 1) {
     RowArgs R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
     R.ctx = pl->ctx; R.scale = pl->scale_single; R.canon_out = 1; R.nrows = batch;
+    R.psi_in = psi_in; R.psi_out = psi_out;
     return launch_row(cx, ROW_MUL, pl->hclass, pl->lt[0], R, st);
   }
   // One launch per pass over the whole resident batch.  (Cutting the batch into cache-sized launch
@@ -451,6 +476,7 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     if (lv == 0) { C.fsa = pl->fsa_fwd; C.logC2 = pl->logC2; }
     C.nblocks = ((long long)batch << pl->logL) >> logN;
     C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
+    if (lv == 0 && psi_in) { C.psi = psi_in; C.nvalid = 0; }
     if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, st)) return rc;
     logN = C.logS;
   }
@@ -465,6 +491,7 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
     if (lv == 0) { C.fsa = pl->fsa_inv; C.logC2 = pl->logC2; }
     C.nblocks = ((long long)batch << pl->logL) >> logNl;
+    if (lv == 0 && psi_out) C.psi = psi_out;
     if (int rc = launch_col(cx, true, pl->hclass, pl->lt[lv], C, 1, st)) return rc;
   }
   return 0;
@@ -723,6 +750,10 @@ static int dev_negacyclic_multiply(Context *cx, const uint32_t *a, const uint32_
   Plan *pl; Twist *tw;
   if (int rc = get_plan(cx, p, logL, false, &pl)) return rc;
   if (int rc = get_twist(cx, p, logL, &tw)) return rc;
+  // one- and two-pass plans apply psi^i inside their first and last pass (two-pass plans use full-line column tiles,
+  // the only shape with a twisted variant); three-pass plans go through separate element-wise passes
+  static const bool unfused = [] { const char *e = getenv("NTTX_TWIST_UNFUSED"); return e && atoi(e) != 0; }();
+  if (pl->npass <= 2 && !unfused) return dev_cyclic_multiply(cx, pl, a, b, c, batch, st, 0, tw->fwd, tw->inv);
   const long long len = 1ll << logL;
   const size_t vec = (size_t)batch * len * 4;
   if (int rc = cx->pa.ensure(vec)) return rc;

@@ -474,51 +474,76 @@ struct RowArgs {
   uint32_t scale;        // ROW_MUL: extra Montgomery factor applied to the pointwise product (0 = none)
   int canon_out;         // fully reduce outputs to [0,p)
   long long nrows;       // total transforms (batch * L / T)
+  // negacyclic products (TWIST kernels, rows = whole vectors): inputs are multiplied by psi_in[i] = psi^i on
+  // the way in and outputs by psi_out[i] = psi^-i on the way out (Montgomery form, T words each)
+  const uint32_t *psi_in, *psi_out;
 };
 
-template <class L>
-__device__ __forceinline__ void row_load(uint32_t *s, const uint32_t *in, long long row0, long long nrows) {
+template <class L, int H = 2, bool TW = false>
+__device__ __forceinline__ void row_load(uint32_t *s, const uint32_t *in, long long row0, long long nrows,
+                                         const uint32_t *psi = nullptr, const Arith<H> *M = nullptr) {
   constexpr int T = L::T;
+  constexpr int KANY = Arith<H>::KANY;
   if constexpr (T >= 4) {
     constexpr int NV4 = L::NT * T / 4;
     for (int v = threadIdx.x; v < NV4; v += L::NTHR) {
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (row0 + c < nrows) x = *reinterpret_cast<const uint4 *>(in + (row0 + c) * T + j);
+      if (row0 + c < nrows) {
+        x = *reinterpret_cast<const uint4 *>(in + (row0 + c) * T + j);
+        if constexpr (TW) {
+          const uint4 f = *reinterpret_cast<const uint4 *>(psi + j);
+          x.x = M->mul(V<KANY>{x.x}, f.x).v; x.y = M->mul(V<KANY>{x.y}, f.y).v;
+          x.z = M->mul(V<KANY>{x.z}, f.z).v; x.w = M->mul(V<KANY>{x.w}, f.w).v;
+        }
+      }
       *reinterpret_cast<uint4 *>(s + L::addr(c, j)) = x;
     }
   } else {
     for (int v = threadIdx.x; v < L::NT * T; v += L::NTHR) {
       const int c = v / T, j = v % T;
-      s[L::addr(c, j)] = (row0 + c < nrows) ? in[(row0 + c) * T + j] : 0u;
+      uint32_t x = (row0 + c < nrows) ? in[(row0 + c) * T + j] : 0u;
+      if constexpr (TW) x = M->mul(V<KANY>{x}, psi[j]).v;
+      s[L::addr(c, j)] = x;
     }
   }
 }
 
-template <class L, int H>
+// TW: stored values are first multiplied by psi[j] (and then always fully reduced)
+template <class L, int H, bool TW = false>
 __device__ __forceinline__ void row_store(const uint32_t *s, uint32_t *out, long long row0, long long nrows,
-                                          const Arith<H> &M, bool canon) {
+                                          const Arith<H> &M, bool canon, const uint32_t *psi = nullptr) {
   // stored values are below KI*p (the last round of either direction is asked for that)
   constexpr int T = L::T;
+  constexpr int KI = Arith<H>::KI;
   if constexpr (T >= 4) {
     constexpr int NV4 = L::NT * T / 4;
     for (int v = threadIdx.x; v < NV4; v += L::NTHR) {
       const int c = (v * 4) >> L::LOGT, j = (v * 4) & (T - 1);
       if (row0 + c < nrows) {
         uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c, j));
-        if (canon) { x.x = M.canon(V<Arith<H>::KI>{x.x}); x.y = M.canon(V<Arith<H>::KI>{x.y}); x.z = M.canon(V<Arith<H>::KI>{x.z}); x.w = M.canon(V<Arith<H>::KI>{x.w}); }
+        if constexpr (TW) {
+          const uint4 f = *reinterpret_cast<const uint4 *>(psi + j);
+          x.x = M.canon(M.mul(V<KI>{x.x}, f.x)); x.y = M.canon(M.mul(V<KI>{x.y}, f.y));
+          x.z = M.canon(M.mul(V<KI>{x.z}, f.z)); x.w = M.canon(M.mul(V<KI>{x.w}, f.w));
+        } else if (canon) { x.x = M.canon(V<KI>{x.x}); x.y = M.canon(V<KI>{x.y}); x.z = M.canon(V<KI>{x.z}); x.w = M.canon(V<KI>{x.w}); }
         *reinterpret_cast<uint4 *>(out + (row0 + c) * T + j) = x;
       }
     }
   } else {
     for (int v = threadIdx.x; v < L::NT * T; v += L::NTHR) {
       const int c = v / T, j = v % T;
-      if (row0 + c < nrows) { uint32_t x = s[L::addr(c, j)]; out[(row0 + c) * T + j] = canon ? M.canon(V<Arith<H>::KI>{x}) : x; }
+      if (row0 + c < nrows) {
+        uint32_t x = s[L::addr(c, j)];
+        if constexpr (TW) x = M.canon(M.mul(V<KI>{x}, psi[j]));
+        else if (canon) x = M.canon(V<KI>{x});
+        out[(row0 + c) * T + j] = x;
+      }
     }
   }
 }
 
-template <int LOGT, int MODE, int H>
+template <int LOGT, int MODE, int H, bool TWIST = false>
 __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
   using L = RowLayout<LOGT>;
   constexpr int T = L::T;
@@ -534,8 +559,8 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
 
   for (long long row0 = (long long)blockIdx.x * L::NT; row0 < A.nrows; row0 += (long long)gridDim.x * L::NT) {
     __syncthreads();  // previous tile fully stored before LDS is overwritten
-    row_load<L>(sa, A.in0, row0, A.nrows);
-    if (MODE == ROW_MUL) row_load<L>(sb, A.in1, row0, A.nrows);
+    row_load<L, H, TWIST>(sa, A.in0, row0, A.nrows, A.psi_in, &M);
+    if (MODE == ROW_MUL) row_load<L, H, TWIST>(sb, A.in1, row0, A.nrows, A.psi_in, &M);
     __syncthreads();
     constexpr int KFc = Arith<H>::KF, KIc = Arith<H>::KI;
     if (MODE == ROW_FWD) {         // inputs canonical or fresh from a constant multiply (< 2p)
@@ -554,7 +579,7 @@ __global__ void __launch_bounds__(WG) row_kernel(RowArgs A) {
       dit_tail<L, LOGT, H>(v, twi, M);
     }
     __syncthreads();
-    row_store<L, H>(sa, A.out, row0, A.nrows, M, A.canon_out != 0);
+    row_store<L, H, TWIST>(sa, A.out, row0, A.nrows, M, A.canon_out != 0, A.psi_out);
   }
 }
 
@@ -575,8 +600,10 @@ constexpr int ROW9_PAD = 576;  // 512 + 8 pad words per 64
 #endif
 // CANON: outputs fully reduced (single-pass products); otherwise they are left unreduced for the
 // inverse column pass, which multiplies them by its four-step constants first.
-template <int H, bool CANON>
+// TWIST (with CANON): negacyclic product of 512-point vectors, the psi factors applied in registers.
+template <int H, bool CANON, bool TWIST = false>
 __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A) {
+  static_assert(!TWIST || CANON, "the twisted product is a single-pass product");
   __shared__ __attribute__((aligned(16))) uint32_t lds[(WG / 64) * 2 * ROW9_PAD];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row addresses stay in SGPRs
@@ -606,6 +633,13 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
     for (int q = 0; q < 8; ++q) { na[q] = pa[lane + 64 * q]; nb[q] = pb[lane + 64 * q]; }
   }
   for (; row < A.nrows; row += nwaves) {
+    if constexpr (TWIST) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t f = A.psi_in[lane + 64 * q];
+        na[q] = M.mul(V<KANY>{na[q]}, f).v; nb[q] = M.mul(V<KANY>{nb[q]}, f).v;
+      }
+    }
     // forward round 1 (distances 256, 128, 64)
     r8_dif<H, false, false, Arith<H>::KROW, KF>(na, wf1, M);
     r8_dif<H, false, false, Arith<H>::KROW, KF>(nb, wf1, M);
@@ -657,10 +691,15 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = sa[o1 + 72 * q];
     // inverse round 3 (64, 128, 256)
-    r8_dit<H, false, KI, (CANON ? 1 : KANY)>(a, wi1, M);
+    r8_dit<H, false, KI, ((CANON && !TWIST) ? 1 : KANY)>(a, wi1, M);
     uint32_t *po = A.out + row * 512;
+    if constexpr (TWIST) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) po[lane + 64 * q] = CANON ? M.fix1(a[q]) : M.raw_out(a[q]);
+      for (int q = 0; q < 8; ++q) po[lane + 64 * q] = M.canon(M.mul(V<KANY>{a[q]}, A.psi_out[lane + 64 * q]));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) po[lane + 64 * q] = CANON ? M.fix1(a[q]) : M.raw_out(a[q]);
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -736,7 +775,8 @@ __device__ __forceinline__ void long_edge(uint32_t *s, const uint32_t *tw, const
   }
 }
 
-template <int LOGT, int H>
+// TWIST: negacyclic product of whole vectors (single pass, canonical output), psi factors applied in registers.
+template <int LOGT, int H, bool TWIST = false>
 __global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(RowArgs A) {
   using L = LongRowLayout<LOGT>;
   constexpr int T = L::T, NTHR = L::NTHR;
@@ -774,6 +814,10 @@ __global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(
       for (int q = 0; q < 8; ++q) xa[q] = pa[g + q * D1];
 #pragma unroll
       for (int m = 1; m < 8; ++m) w1[m] = A.tw_fwd[g + m * D1];
+      if constexpr (TWIST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xa[q] = M.mul(V<KANY>{xa[q]}, A.psi_in[g + q * D1]).v;
+      }
       r8_dif<H, false, false, Arith<H>::KROW, KF>(xa, w1, M);
 #pragma unroll
       for (int q = 0; q < 8; ++q) sa[L::padj(g + q * D1)] = xa[q];
@@ -793,6 +837,10 @@ __global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(
 #pragma unroll
           for (int m = 1; m < 8; ++m) w1[m] = A.tw_fwd[g + m * D1];
         }
+      }
+      if constexpr (TWIST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xb[q] = M.mul(V<KANY>{xb[q]}, A.psi_in[g + q * D1]).v;
       }
       r8_dif<H, false, false, Arith<H>::KROW, KF>(xb, w1, M);
 #pragma unroll
@@ -822,7 +870,11 @@ __global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(
       for (int m = 1; m < 8; ++m) w[m] = A.tw_inv[g + m * D1];
 #pragma unroll
       for (int q = 0; q < 8; ++q) x[q] = sa[L::padj(g + q * D1)];
-      if (A.canon_out) {
+      if constexpr (TWIST) {
+        r8_dit<H, false, KI, KANY>(x, w, M);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) po[g + q * D1] = M.canon(M.mul(V<KANY>{x[q]}, A.psi_out[g + q * D1]));
+      } else if (A.canon_out) {
         r8_dit<H, false, KI, 1>(x, w, M);
 #pragma unroll
         for (int q = 0; q < 8; ++q) po[g + q * D1] = M.fix1(x[q]);
@@ -872,6 +924,7 @@ struct ColArgs {
   int canon_out;
   long long nblocks;      // batch * L / N
   long long nvalid;       // ZHI kernels: words of each block that hold data; the rest reads as zero
+  const uint32_t *psi;    // TWIST kernels (outermost pass of a negacyclic product): psi^i forward, psi^-i inverse, N words
 };
 
 // Each thread moves PER = T*COLS/(4*NTHR) 16-byte pieces of a tile; LPR = COLS/4 lanes cover one
@@ -882,8 +935,11 @@ struct ColArgs {
 // FS2: the four-step factor of column s = h 2^logC2 + l is the product fsa[j][h] * fs[j][l] of two
 // small tables (one more multiplication per point) instead of an N-word table read: for the long
 // outer pass of three-pass lengths, where that table would double the pass's HBM traffic.
-template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false>
+// TWIST: the pass is the outermost one of a negacyclic product: forward inputs are multiplied by psi^i as
+// they are read, inverse outputs by psi^-i before the canonical store.
+template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false, bool TWIST = false>
 __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColArgs A) {
+  static_assert(!TWIST || (!ZHI && !FS2), "twisted passes read whole vectors and use the plain four-step table");
   using L = ColLayout<LOGT, LOGC, NTHR>;
   constexpr int T = L::T, COLS = L::COLS;
   constexpr int LPR = COLS / 4, LOG_LPR = LOGC - 2;
@@ -969,6 +1025,11 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
       uint4 x = nx[k];
       const int j = j0 + k * RSTEP;
       if (INV) fs_mul(x, fbase, j);
+      if constexpr (TWIST && !INV) {
+        const uint4 f = *reinterpret_cast<const uint4 *>(A.psi + fbase + ((long long)j << logS) + c4);
+        x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
+        x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
+      }
       *reinterpret_cast<uint4 *>(s + L::addr(c4, j)) = x;
     }
     if (t0 + gridDim.x < ntiles) {
@@ -989,7 +1050,11 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
       const int j = j0 + k * RSTEP;
       uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c4, j));
       if (!INV) fs_mul(x, fbase, j);
-      if (A.canon_out) {   // forward results are < 2p after the multiply, inverse results < KI*p
+      if constexpr (TWIST && INV) {
+        const uint4 f = *reinterpret_cast<const uint4 *>(A.psi + fbase + ((long long)j << logS) + c4);
+        x.x = M.canon(M.mul(V<Arith<H>::KI>{x.x}, f.x)); x.y = M.canon(M.mul(V<Arith<H>::KI>{x.y}, f.y));
+        x.z = M.canon(M.mul(V<Arith<H>::KI>{x.z}, f.z)); x.w = M.canon(M.mul(V<Arith<H>::KI>{x.w}, f.w));
+      } else if (A.canon_out) {   // forward results are < 2p after the multiply, inverse results < KI*p
         constexpr int KS = INV ? Arith<H>::KI : Arith<H>::KM;
         x.x = M.canon(V<KS>{x.x}); x.y = M.canon(V<KS>{x.y}); x.z = M.canon(V<KS>{x.z}); x.w = M.canon(V<KS>{x.w});
       }

@@ -398,10 +398,17 @@ def test_device_linear_product_skips_padding(nttx, oracle, n):
         assert not c[i, 2 * n - 1:].any()
 
 
-@pytest.mark.parametrize("p,log_len,batch", [(469762049, 3, 2), (998244353, 10, 3), (1224736769, 13, 2), (469762049, 18, 2)])
+_NEGA = ([(469762049, k, 3) for k in range(1, 17)] + [(998244353, k, 2) for k in (4, 8, 9, 10, 12, 14, 15, 17)]
+         + [(1224736769, k, 2) for k in (6, 9, 11, 13, 16)] + [(469762049, 18, 2), (469762049, 20, 1), (998244353, 21, 1),
+                                                               (469762049, 24, 1)])
+
+
+@pytest.mark.parametrize("p,log_len,batch", _NEGA)
 def test_negacyclic_product(nttx, oracle, p, log_len, batch):
     """c = a b mod (x^len + 1, p): equals lin[i] - lin[i + len] of the linear product, which the
-    oracle gives as a cyclic product of the zero-padded inputs (ntt_compute, main.cc:185-209)."""
+    oracle gives as a cyclic product of the zero-padded inputs (ntt_compute, main.cc:185-209).  Every
+    kernel family that applies the psi factors itself (tiled rows, 512-point rows, long rows, two-pass
+    plans) on all modulus classes, and a three-pass length (separate element-wise passes)."""
     import torch
     L = 1 << log_len
     a = np.stack([oracle.fill_random(L, 300 + i, p) for i in range(batch)]).astype(np.uint32)

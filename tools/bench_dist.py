@@ -5,6 +5,7 @@
   --workload crt       4-prime CRT products of n = 2^17 u64 coefficients, primes dealt to ranks,
                        one all-to-all of residue slices per step (ntt_amd.distributed.CrtSharded)
   --workload batch     4096 independent products of length 2^16 / 2^17, batch dealt to ranks, no collective
+  --workload nega      batch of negacyclic products (mod x^N + 1) of N = 2^log-len coefficients, batch dealt to ranks
   --workload fourstep  one product of length 2^24..2^26 split by columns, two all-to-alls
                        (ntt_amd.distributed.FourStepSharded); with one rank it is also compared
                        with the single-GPU three-pass plan
@@ -46,7 +47,7 @@ def timed(fn, steps, warmup, torch, dist, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="crt", choices=("crt", "batch", "fourstep"))
+    ap.add_argument("--workload", default="crt", choices=("crt", "batch", "fourstep", "nega"))
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
@@ -113,6 +114,22 @@ def main():
         out.update(batch=B, log2_len=logL, poly_mults_per_s=B * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
                    us_per_mult_per_gpu=dt / args.steps / nb * 1e6, passes=ntt_amd.plan_info(L),
                    model_GBs_per_gpu=52 * L * nb * args.steps / dt / 1e9)
+    elif args.workload == "nega":
+        logN = args.log_len or 12
+        N, B = 1 << logN, args.batch or 4096
+        lo, hi = shard_range(B, rank, world)
+        nb = hi - lo
+        a = torch.randint(0, P32, (nb, N), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+        b = torch.randint(0, P32, (nb, N), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+        c = torch.empty_like(a)
+        st = torch.cuda.current_stream().cuda_stream
+        dt = timed(lambda: ntt_amd.dev_negacyclic_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), N, P32, nb, st),
+                   args.steps, args.warmup, torch, dist, dev)
+        dtc = timed(lambda: ntt_amd.dev_cyclic_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), N, P32, nb, st),
+                    args.steps, args.warmup, torch, dist, dev)
+        out.update(batch=B, log2_len=logN, products_per_s=B * args.steps / dt, us_per_product_per_gpu=dt / args.steps / nb * 1e6,
+                   cyclic_us_per_product_per_gpu=dtc / args.steps / nb * 1e6, passes=ntt_amd.plan_info(N),
+                   moved_GBs_12N=12 * N * nb * args.steps / dt / 1e9)
     else:
         logL = args.log_len or 24
         L = 1 << logL
