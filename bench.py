@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-check", action="store_true", help="ablation builds only: skip the oracle spot-check")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-context", action="store_true", help="profiling runs: skip the device-copy and batch-1 measurements "
+                    "after the timed region, so a kernel trace holds only the benchmark's own launches")
     args = ap.parse_args()
 
     import numpy as np
@@ -185,7 +187,7 @@ def main():
     # two context figures, outside the timed region: what a plain device-to-device copy of the same
     # buffers reaches on this GPU (read L*B words + write L*B words), and the latency of ONE resident product
     copy_gbs = lat1_us = None
-    if rank == 0 and not args.no_events:
+    if rank == 0 and not args.no_events and not args.no_context:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
             c.copy_(a)

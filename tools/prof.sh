@@ -6,7 +6,7 @@ tag=${1:-r1}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 200 --warmup 50 --no-cpu"
+BENCH="python3 bench.py --steps 200 --warmup 50 --no-cpu --no-context"
 timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH > $out/trace.log 2>&1
 timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $BENCH > $out/pmc_fetch.log 2>&1
 timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $BENCH > $out/pmc_write.log 2>&1
