@@ -31,8 +31,8 @@ extern "C" {
 
 /* Which arithmetic path a (p, n) pair takes. */
 #define NTTX_PATH_DIRECT32 0 /* one NTT modulo p itself: p < 2^31 prime, 2^k | p-1 (monttry2.cpp get_result) */
-#define NTTX_PATH_CRT4 1     /* the four 32-bit NTT primes + CRT of main.cc:245-338 (as few of the largest of them
-                              * as keep n*(p-1)^2 below their product: same coefficients) */
+#define NTTX_PATH_CRT4 1     /* the four 32-bit NTT primes + CRT of main.cc:245-338 (as few of them as keep
+                              * n*(p-1)^2 below their product: same coefficients) */
 #define NTTX_PATH_DIRECT64 2 /* one NTT modulo p itself on 64-bit lanes: 2^31 <= p < 2^62 prime, 2^k | p-1 */
 
 /* Select the GPU of this process and build the context (one process per GPU).

@@ -551,12 +551,23 @@ static int fill_crt_args(CrtArgs &A, uint64_t p) { const int all[4] = {0, 1, 2, 
 
 // exactness bound of the CRT path: every coefficient of the integer product, at most
 // n*(amax)*(bmax) with amax,bmax <= p-1, must stay below the product of the moduli used
-// (cf. "sum % M" main.cc:330).  The moduli are kCrtPrimes[first..3].
-static bool crt_bound_ok(uint64_t p, int n, int first = 0) {
+// (cf. "sum % M" main.cc:330).  The moduli are kCrtPrimes[first..first+count-1].
+static bool crt_bound_ok(uint64_t p, int n, int first = 0, int count = 4) {
   long double lim = 1;
-  for (int k = first; k < 4; ++k) lim *= (long double)kCrtPrimes[k];
+  for (int k = first; k < first + count; ++k) lim *= (long double)kCrtPrimes[k];
   const long double need = (long double)n * (long double)(p - 1) * (long double)(p - 1);
   return need < lim * 0.999L;
+}
+// the fewest primes that keep the product exact: the smallest ones where they suffice (their transforms are the
+// cheapest: more lazy-reduction headroom, signed lanes), else the largest ones
+static void crt_pick(uint64_t p, int n, int *first, int *count) {
+  static const bool four_only = [] { const char *e = getenv("NTTX_CRT_FOUR"); return e && atoi(e) != 0; }();
+  *first = 0; *count = 4;
+  if (four_only) return;
+  for (int ns = 1; ns < 4; ++ns) {
+    if (crt_bound_ok(p, n, 0, ns)) { *first = 0; *count = ns; return; }
+    if (crt_bound_ok(p, n, 4 - ns, ns)) { *first = 4 - ns; *count = ns; return; }
+  }
 }
 
 static int log2_ceil_len(int n) {  // main.cc:278-279: smallest power of two >= 2n
@@ -566,18 +577,16 @@ static int log2_ceil_len(int n) {  // main.cc:278-279: smallest power of two >= 
 }
 
 // d_ab[b][0..2n-2] from u64 device inputs through the CRT path: the reference's four primes
-// (main.cc:245-248), or only the largest three, two or one of them where n*(p-1)^2 stays below their
-// product (three for every modulus below 2^36 at n = 2^17, two below 2^21): fewer transforms, the
-// same coefficients
+// (main.cc:245-248), or only three, two or one of them where n*(p-1)^2 stays below their product
+// (three for every modulus below 2^36 at n = 2^17, two below 2^21): fewer transforms, the same
+// coefficients
 static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_ab, int n, uint64_t p,
                             int batch, hipStream_t st) {
   const int logL = log2_ceil_len(n);
   if (logL > 21) return fail(NTTX_ERANGE, "length 2^%d exceeds the CRT prime set (2^21)", logL);
   if (!crt_bound_ok(p, n)) return fail(NTTX_ERANGE, "n*(p-1)^2 exceeds the product of the CRT primes");
-  static const bool four_only = [] { const char *e = getenv("NTTX_CRT_FOUR"); return e && atoi(e) != 0; }();
-  int first = 0;                                   // use kCrtPrimes[first..3]: as few of the largest as the bound allows
-  if (!four_only) for (int f = 3; f >= 1; --f) if (crt_bound_ok(p, n, f)) { first = f; break; }
-  const int ns = 4 - first;
+  int first, ns;
+  crt_pick(p, n, &first, &ns);
   int sel[4];
   for (int k = 0; k < ns; ++k) sel[k] = first + k;
   const long long len = 1ll << logL;

@@ -84,19 +84,20 @@ def test_crt_path_small(nttx, oracle, p):
 
 
 def test_crt_fewer_primes_bound(nttx, oracle):
-    """The CRT route uses only the largest three, two or one of the four primes where n*(p-1)^2 stays
-    below their product.  Worst-case inputs (every coefficient p-1, so the middle coefficient of the
+    """The CRT route uses only three, two or one of the four primes (the smallest where they suffice, else
+    the largest) where n*(p-1)^2 stays below their product.  Worst-case inputs (every coefficient p-1, so the middle coefficient of the
     integer product reaches n*(p-1)^2) on both sides of each bound, plus random inputs, against the
     four-prime oracle."""
-    primes = (998244353, 1004535809, 1224736769)
+    primes = (469762049, 998244353, 1004535809, 1224736769)
     for n in (1000, 4096, 65536):
         moduli = [2147483647, (1 << 36) - 5, 65537, 97, 12345678]
-        for first in range(3):
-            prod = 1
-            for m in primes[first:]:
-                prod *= m
-            edge = int((prod * 0.999 / n) ** 0.5)
-            moduli += [edge - edge // 100000 - 3, edge + edge // 100000 + 3]
+        for ns in (1, 2, 3):
+            for subset in (primes[:ns], primes[4 - ns:]):     # the cheapest and the largest ns primes
+                prod = 1
+                for m in subset:
+                    prod *= m
+                edge = int((prod * 0.999 / n) ** 0.5)
+                moduli += [edge - edge // 100000 - 3, edge + edge // 100000 + 3]
         for p in moduli:
             if nttx.path_for(p, n) != nttx.PATH_CRT4:
                 p += 1                      # an NTT-friendly prime would take a direct route: step off it
