@@ -127,6 +127,12 @@ int nttx_dev_ntt_u32(void *d_x, int len, uint32_t p, int inverse, int bit_revers
 /* The k-th modulus of the CRT path, k = 0..3 (the constants of main.cc:245-248). */
 int nttx_crt_prime(int k, uint32_t *prime);
 
+/* Which of those moduli nttx_poly_multiply_crt_u64 / nttx_dev_crt_multiply_u64 use for n coefficients modulo p:
+ * main.cc:245-338 always takes all four; here as few of them as keep n*(p-1)^2 below their product (the
+ * coefficients are the same).  Writes the moduli to primes[0..count-1] and returns count (1..4), or
+ * NTTX_ERANGE when even four do not suffice.  Needs no device. */
+int nttx_crt_primes_for(uint64_t p, int n, uint32_t primes[4]);
+
 /* The per-prime part of the CRT path (residue split main.cc:292-303 and ntt_compute_omp
  * main.cc:306-311) for the primes selected by prime_mask (bit k = modulus k): d_res receives, for
  * each selected prime in ascending k, the [batch][len] canonical u32 residues of the products

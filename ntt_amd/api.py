@@ -38,6 +38,7 @@ _SIGS = [
     ("nttx_dev_crt_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_dev_ntt_u32", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_crt_prime", C.c_int, [C.c_int, _u32p]),
+    ("nttx_crt_primes_for", C.c_int, [C.c_uint64, C.c_int, _u32p]),
     ("nttx_dev_crt_residues_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_dev_crt_recombine_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint64, C.c_void_p]),
     ("nttx_dev_colpass_u32", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
@@ -229,6 +230,14 @@ def crt_prime(k: int) -> int:
     v = C.c_uint32(0)
     _check(lib().nttx_crt_prime(k, C.byref(v)))
     return v.value
+
+
+def crt_primes_for(p: int, n: int):
+    """The CRT moduli the engine uses for n coefficients modulo p (as few of main.cc:245-248's four as keep the
+    product exact); needs no device."""
+    v = (C.c_uint32 * 4)()
+    k = _check(lib().nttx_crt_primes_for(p, n, v))
+    return [int(v[i]) for i in range(k)]
 
 
 def dev_crt_residues_u64(d_a: int, d_b: int, d_res: int, n: int, prime_mask: int, batch: int, stream: int = 0):

@@ -941,6 +941,15 @@ int nttx_dev_colpass_u32(void *d_x, int log_len, int log_t, long long col0, int 
   return dev_colpass(cx, (uint32_t *)d_x, log_len, log_t, col0, cols, p, inverse != 0, zero_hi != 0, (hipStream_t)stream);
 }
 
+int nttx_crt_primes_for(uint64_t p, int n, uint32_t primes[4]) {
+  if (n < 1 || p < 2 || p >= (1ull << 63) || !primes) return fail(NTTX_EINVAL, "bad arguments");
+  if (!crt_bound_ok(p, n)) return fail(NTTX_ERANGE, "n*(p-1)^2 exceeds the product of the CRT primes");
+  int first, ns;
+  crt_pick(p, n, &first, &ns);
+  for (int k = 0; k < ns; ++k) primes[k] = kCrtPrimes[first + k];
+  return ns;
+}
+
 int nttx_crt_prime(int k, uint32_t *prime) {
   if (k < 0 || k >= 4 || !prime) return fail(NTTX_EINVAL, "CRT prime index out of range");
   *prime = kCrtPrimes[k];

@@ -65,6 +65,28 @@ def test_path_selection():
     assert ntt_amd.path_for(7340033 * 3, 4) == C            # composite
 
 
+def test_crt_prime_selection():
+    """As few CRT primes as keep n*(p-1)^2 below their product; the smallest ones where they suffice."""
+    import ntt_amd
+    primes = [469762049, 998244353, 1004535809, 1224736769]
+    n = 1 << 17
+    assert ntt_amd.crt_primes_for(1337006139375617, n) == primes           # id 4's modulus: all four
+    assert ntt_amd.crt_primes_for(2147483647, n) == primes[:3]
+    assert ntt_amd.crt_primes_for((1 << 36) - 5, n) == primes[1:]          # needs the three largest
+    assert ntt_amd.crt_primes_for(65537, n) == primes[:2]
+    assert ntt_amd.crt_primes_for(97, 4) == primes[:1]
+    for ns in (1, 2, 3):
+        for subset in (primes[:ns], primes[4 - ns:]):
+            prod = 1
+            for m in subset:
+                prod *= m
+            edge = int((prod * 0.999 / n) ** 0.5)
+            assert len(ntt_amd.crt_primes_for(edge - edge // 100000 - 3, n)) <= ns
+            assert len(ntt_amd.crt_primes_for(edge + edge // 100000 + 3, n)) >= (ns if subset == primes[:ns] else ns + 1)
+    with pytest.raises(ntt_amd.NttxError):
+        ntt_amd.crt_primes_for((1 << 61) - 1, n)
+
+
 def test_plan_decomposition():
     import ntt_amd
     assert ntt_amd.plan_info(2) == [1]

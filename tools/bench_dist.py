@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--log-len", type=int, default=0)
+    ap.add_argument("--p", type=int, default=0, help="batch / nega workloads: another 32-bit NTT prime than 469762049")
     args = ap.parse_args()
 
     import torch
@@ -59,6 +60,9 @@ def main():
     from ntt_amd.distributed import CrtSharded, FourStepSharded, HipEngine, ThreadComm, TorchComm
     from ntt_amd.sharding import shard_range
 
+    global P32
+    if args.p:
+        P32 = args.p
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,7 +115,7 @@ def main():
         torch.cuda.synchronize()
         ntt_amd.profile_enable(False)
         out["kernels_ms_per_step"] = {k: round(v[0] / 10, 4) for k, v in ntt_amd.profile_read().items() if v[1] > 0}
-        out.update(batch=B, log2_len=logL, poly_mults_per_s=B * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
+        out.update(batch=B, p=P32, log2_len=logL, poly_mults_per_s=B * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
                    us_per_mult_per_gpu=dt / args.steps / nb * 1e6, passes=ntt_amd.plan_info(L),
                    model_GBs_per_gpu=52 * L * nb * args.steps / dt / 1e9)
     elif args.workload == "nega":
