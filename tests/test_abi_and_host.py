@@ -25,6 +25,31 @@ def test_library_exports_every_declared_symbol():
     assert sorted(ntt_amd.exported_symbols()) == names
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/nttx.h compiles as C99 (no C++ or torch types in the boundary) and a C program linked
+    against libnttx.so resolves the device-free queries."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "nttx.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  int lt[3]; uint32_t pr[4];\n"
+        "  int np = nttx_plan_info(1 << 18, lt);\n"
+        "  int nc = nttx_crt_primes_for(1337006139375617ull, 131072, pr);\n"
+        "  int path = nttx_path_for(469762049ull, 131072);\n"
+        '  printf("%d %d %d %d %d %u\\n", np, lt[0], lt[1], nc, path, pr[0]);\n'
+        "  return nttx_poly_multiply_i32(0, 0, 0, 0, 7340033) == 0;   /* must fail cleanly: no device call made */\n"
+        "}\n")
+    exe = tmp_path / "abi"
+    lib = os.path.join(root, "ntt_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", lib, "-lnttx", f"-Wl,-rpath,{lib}"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["2", "9", "9", "4", str(0), "469762049"], r.stdout
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a device the product must fail loudly, never compute on the host."""
     import torch
