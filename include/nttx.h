@@ -185,6 +185,9 @@ int nttx_profile_read(int kind, double *total_ms, long long *launches);
 /* Decomposition chosen for a length: writes up to 3 pass sizes (log2) into logt, returns
  * the number of passes, or a negative code. */
 int nttx_plan_info(int len, int *logt);
+/* The same for the 64-bit-lane path (nttx_poly_multiply_direct_u64 and friends), where the longest row pass
+ * depends on the headroom the modulus leaves in 64 bits. */
+int nttx_plan_info_u64(int len, uint64_t p, int *logt);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ _SIGS = [
     ("nttx_profile_reset", C.c_int, []),
     ("nttx_profile_read", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     ("nttx_plan_info", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    ("nttx_plan_info_u64", C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_int)]),
 ]
 
 
@@ -110,6 +111,12 @@ def path_for(p: int, n: int) -> int:
 def plan_info(length: int):
     lt = (C.c_int * 3)()
     k = _check(lib().nttx_plan_info(length, lt))
+    return list(lt[:k])
+
+
+def plan_info_u64(length: int, p: int):
+    lt = (C.c_int * 3)()
+    k = _check(lib().nttx_plan_info_u64(length, p, lt))
     return list(lt[:k])
 
 

@@ -845,6 +845,15 @@ int nttx_path_for(uint64_t p, int n) {
   return direct_ok(p, k) ? NTTX_PATH_DIRECT32 : engine64_ok(p, k) ? NTTX_PATH_DIRECT64 : NTTX_PATH_CRT4;
 }
 
+int nttx_plan_info_u64(int len, uint64_t p, int *logt) {
+  if (len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two >= 2");
+  int k = 0; while ((1 << k) < len) ++k;
+  int lt[3] = {0, 0, 0};
+  const int np = engine64_decompose(k, p, lt);
+  if (logt) for (int i = 0; i < np; ++i) logt[i] = lt[i];
+  return np;
+}
+
 int nttx_plan_info(int len, int *logt) {
   if (len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two >= 2");
   int k = 0; while ((1 << k) < len) ++k;

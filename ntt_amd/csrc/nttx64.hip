@@ -32,13 +32,23 @@ const char *engine64_error() { return g_err64.c_str(); }
 #define HIPCHK64(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
   return fail64(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-constexpr int kMaxRow64 = 11, kMinCol64 = 6, kMaxCol64 = 9, kMaxLog64 = 29;
+constexpr int kMaxRow64 = 13, kMinCol64 = 6, kMaxCol64 = 9, kMaxLog64 = 29;
+// Longest row pass for modulus p.  Rows of 2^12 and 2^13 points take one whole workgroup each
+// (NTTX_LONGROW64=0: the plans without them, for A/B runs).  In the lazy class (p < 2^51) a forward
+// pass of k stages on values below 2p ends below 2^(k+1) p, which has to fit 64 bits: k <= 63 - bits(p).
+static int max_row64(uint64_t p) {
+  static const int m = [] { const char *e = getenv("NTTX_LONGROW64"); return (e && atoi(e) == 0) ? 11 : kMaxRow64; }();
+  if (p >= (1ull << 51)) return m;                       // Harvey butterflies: values never leave [0, 2p)
+  int bits = 0; while (bits < 64 && (p >> bits)) ++bits;   // p < 2^bits
+  return std::max(11, std::min(m, 63 - bits));
+}
 
-int engine64_decompose(int k, int lt[3]) {
-  if (k <= kMaxRow64) { lt[0] = k; return 1; }
-  if (k <= kMaxCol64 + kMaxRow64) { lt[0] = std::min(kMaxCol64, k / 2); lt[1] = k - lt[0]; return 2; }
+int engine64_decompose(int k, uint64_t p, int lt[3]) {
+  const int maxrow = max_row64(p);
+  if (k <= maxrow) { lt[0] = k; return 1; }
+  if (k <= kMaxCol64 + maxrow) { lt[0] = std::min(kMaxCol64, k / 2); lt[1] = k - lt[0]; return 2; }
   int row = std::max((k + 2) / 3, k - 2 * kMaxCol64);
-  if (row > kMaxRow64) row = kMaxRow64;
+  if (row > 11) row = 11;
   const int rem = k - row;
   lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
   return 3;
@@ -153,7 +163,7 @@ static int get_plan64(Engine64 *e, uint64_t p, int logL, bool conj, Plan64 **out
   const PrimeCtx64 c = make_ctx64(p);
   HostMont64 M{p, c.npinv, (uint64_t)((((unsigned __int128)1) << 64) % p), c.r2};
   pl->ctx = PrimeArgs64{p, c.npinv, M.one, M.r2};
-  pl->npass = engine64_decompose(logL, pl->lt);
+  pl->npass = engine64_decompose(logL, p, pl->lt);
   const uint64_t g = find_nonresidue64(p);
   uint64_t wL = h_powmod64(g, (p - 1) >> logL, p);                 // primitive 2^logL-th root (main.cc:156)
   if (conj) wL = h_powmod64(wL, p - 2, p);                         // main.cc:157
@@ -189,13 +199,15 @@ static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
 #define NTTX_ROW64_CASE(K) case K: { \
     using Lyt = RowLayout64<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    if constexpr (MODE == 2) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap_row)), dim3(256), 0, st, A); \
-    else hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap_row)), dim3(256), 0, st, A); \
+    const int cap = K >= 12 ? (1 << 20) : cap_row;   /* long rows: one row per workgroup */ \
+    if constexpr (MODE == 2) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
+    else hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
     break; }
   static const int cap_row = env_int64("NTTX_GRID_ROW64", 4096);
   switch (logT) {
     NTTX_ROW64_CASE(1) NTTX_ROW64_CASE(2) NTTX_ROW64_CASE(3) NTTX_ROW64_CASE(4) NTTX_ROW64_CASE(5) NTTX_ROW64_CASE(6)
     NTTX_ROW64_CASE(7) NTTX_ROW64_CASE(8) NTTX_ROW64_CASE(9) NTTX_ROW64_CASE(10) NTTX_ROW64_CASE(11)
+    NTTX_ROW64_CASE(12) NTTX_ROW64_CASE(13)
     default: return fail64(NTTX_ERANGE, "row pass of 2^%d points unsupported", logT);
   }
 #undef NTTX_ROW64_CASE

@@ -146,7 +146,7 @@ struct RowLayout64 {
   static constexpr int TP = T + (T >> 5) * 4;
   static constexpr int NT = (T >= 2048) ? 1 : (2048 >> LOGT);
   static constexpr int WORDS = NT * TP;
-  static constexpr int NTHR = 256;
+  static constexpr int NTHR = (LOGT <= 11) ? 256 : (T / 8);   // longer rows: one row per workgroup, eight points per thread
   __device__ static constexpr int padj(int j) { return j + ((j >> 5) << 2); }
   __device__ static __forceinline__ int addr(int c, int j) { return c * TP + padj(j); }
   template <int LOGU>
@@ -251,7 +251,7 @@ __device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long
 }
 
 template <int LOGT, int MODE, bool SAFE, bool PLO1>
-__global__ void __launch_bounds__(256) row64_kernel(RowArgs64 A) {
+__global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR) row64_kernel(RowArgs64 A) {
   using L = RowLayout64<LOGT>;
   using AR = Arith64<SAFE, PLO1>;
   constexpr int T = L::T;
@@ -308,24 +308,25 @@ __global__ void __launch_bounds__(256) row64_kernel(RowArgs64 A) {
 // registers while the other vector uses the buffer: half the LDS of keeping both vectors
 // resident (twice the workgroups per CU) and two LDS round trips fewer.
 // ------------------------------------------------------------------------------------
-// all rounds of a forward pass but the last (which has R = RL stages at distance 1)
-template <class L, int REM, class AR>
-__device__ __forceinline__ void dif_head64(uint64_t *s, const uint64_t *tw, const AR &M) {
+// all rounds of a forward pass but the last (which has R = RL stages at distance 1); rounds whose
+// twiddles lie within the first TWL table words read the LDS copy twl, the others the table itself
+template <class L, int REM, class AR, int TWL>
+__device__ __forceinline__ void dif_head64(uint64_t *s, const uint64_t *twg, const uint64_t *twl, const AR &M) {
   if constexpr (REM > 3) {
     uint64_t *const v[1] = {s};
-    ntt_round64<L, 3, REM - 3, false, AR, 1, false>(v, tw, M);
+    ntt_round64<L, 3, REM - 3, false, AR, 1, false>(v, (8 << (REM - 3)) <= TWL ? twl : twg, M);
     __syncthreads();
-    dif_head64<L, REM - 3, AR>(s, tw, M);
+    dif_head64<L, REM - 3, AR, TWL>(s, twg, twl, M);
   }
 }
 // all rounds of an inverse pass after the first
-template <class L, int REM, class AR>
-__device__ __forceinline__ void dit_tail64(uint64_t *s, const uint64_t *tw, const AR &M) {
+template <class L, int REM, class AR, int TWL>
+__device__ __forceinline__ void dit_tail64(uint64_t *s, const uint64_t *twg, const uint64_t *twl, const AR &M) {
   if constexpr (REM > 3) {
-    dit_tail64<L, REM - 3, AR>(s, tw, M);
+    dit_tail64<L, REM - 3, AR, TWL>(s, twg, twl, M);
     __syncthreads();
     uint64_t *const v[1] = {s};
-    ntt_round64<L, 3, REM - 3, true, AR, 1, false>(v, tw, M);
+    ntt_round64<L, 3, REM - 3, true, AR, 1, false>(v, (8 << (REM - 3)) <= TWL ? twl : twg, M);
   }
 }
 // the distance-1 round on registers: r[u*NP + q] = point q of the thread's u-th unit
@@ -354,34 +355,41 @@ __device__ __forceinline__ void edge_round64(uint64_t *s, const uint64_t *tw, co
 }
 
 template <int LOGT, bool SAFE, bool PLO1>
-__global__ void __launch_bounds__(256) rowmul64_kernel(RowArgs64 A) {
+__global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1)) rowmul64_kernel(RowArgs64 A) {
   using L = RowLayout64<LOGT>;
   using AR = Arith64<SAFE, PLO1>;
   constexpr int T = L::T;
   constexpr int RL = (LOGT - 1) % 3 + 1;          // stages of the distance-1 round
-  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + 2 * T];
-  uint64_t *sa = lds, *twf = lds + L::WORDS, *twi = twf + T;
+  // stage tables in LDS: whole up to 2^11 points; of longer rows only the first 512 words (the rounds
+  // at distance <= 64), the outer rounds read the tables through the caches
+  constexpr int TWL = (LOGT <= 11) ? T : 512;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + 2 * TWL];
+  uint64_t *sa = lds, *twf = lds + L::WORDS, *twi = twf + TWL;
   const AR M(A.ctx);
-  for (int i = threadIdx.x; i < T; i += L::NTHR) { twf[i] = A.tw_fwd[i]; twi[i] = A.tw_inv[i]; }
+  for (int i = threadIdx.x; i < TWL; i += L::NTHR) { twf[i] = A.tw_fwd[i]; twi[i] = A.tw_inv[i]; }
 
   for (long long row0 = (long long)blockIdx.x * L::NT; row0 < A.nrows; row0 += (long long)gridDim.x * L::NT) {
     uint64_t ra[8], rb[8];
     __syncthreads();
     row_load64<L>(sa, A.in0, row0, A.nrows);
     __syncthreads();
-    dif_head64<L, LOGT, AR>(sa, twf, M);
+    dif_head64<L, LOGT, AR, TWL>(sa, A.tw_fwd, twf, M);
     edge_round64<L, RL, false, true, false, AR>(sa, twf, M, ra);
     __syncthreads();
     row_load64<L>(sa, A.in1, row0, A.nrows);
     __syncthreads();
-    dif_head64<L, LOGT, AR>(sa, twf, M);
+    dif_head64<L, LOGT, AR, TWL>(sa, A.tw_fwd, twf, M);
     edge_round64<L, RL, false, true, false, AR>(sa, twf, M, rb);
-    // pointwise: (a * pre) is below 2p whatever a held, so its product with b (< 2^12 p) fits REDC
+    // pointwise: (a * pre) is below 2p whatever a held, so its product with b (< 2^12 p after up to 11 lazy
+    // stages, p < 2^51) fits REDC; longer lazy rows leave b up to 2^14 p, so b is reduced first
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ra[k] = M.mul(M.mul(ra[k], A.pre), rb[k]);
+    for (int k = 0; k < 8; ++k) {
+      const uint64_t bk = (!SAFE && LOGT >= 12) ? M.mul(rb[k], A.ctx.one) : rb[k];
+      ra[k] = M.mul(M.mul(ra[k], A.pre), bk);
+    }
     edge_round64<L, RL, true, false, true, AR>(sa, twi, M, ra);
     __syncthreads();
-    dit_tail64<L, LOGT, AR>(sa, twi, M);
+    dit_tail64<L, LOGT, AR, TWL>(sa, A.tw_inv, twi, M);
     __syncthreads();
     constexpr int NV2 = L::NT * T / 2;
     for (int v = threadIdx.x; v < NV2; v += L::NTHR) {

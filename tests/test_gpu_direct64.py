@@ -50,7 +50,7 @@ def test_paths_and_small_products(nttx, oracle, name):
 
 
 @pytest.mark.parametrize("name,n", [("lazy_lo1", 4097), ("lazy", 20000), ("lazy_lo1_b", 65536), ("lazy_small", 70001),
-                                    ("lazy_lo1_top", 3000)])
+                                    ("lazy_lo1_top", 3000), ("lazy", 3000), ("lazy_small", 4000), ("lazy_lo1", 2500)])
 def test_two_pass_lengths_vs_crt_oracle(nttx, oracle, name, n):
     p = PRIMES[name]
     a, b = rand(oracle, n, 11, p), rand(oracle, n, 12, p)
@@ -58,7 +58,7 @@ def test_two_pass_lengths_vs_crt_oracle(nttx, oracle, name, n):
     assert np.array_equal(nttx.poly_multiply_direct64(a, b, n, p), want)
 
 
-@pytest.mark.parametrize("name,n", [("safe_lo1", 5000), ("safe", 4100)])
+@pytest.mark.parametrize("name,n", [("safe_lo1", 5000), ("safe", 4100), ("safe_lo1", 3000), ("safe", 4096)])
 def test_two_pass_lengths_safe_class(nttx, oracle, name, n):
     """Moduli beyond the CRT bound: schoolbook oracle."""
     p = PRIMES[name]
@@ -98,8 +98,43 @@ def test_inputs_not_reduced(nttx, oracle):
     assert np.array_equal(nttx.poly_multiply_direct64(big_a, big_b, n, p), oracle.poly_multiply_crt(a, b, p))
 
 
+def _sparse_check(nttx, p, log_len, unit_terms):
+    """Linear product of a dense random a (n = 2^(log_len-1) coefficients) with a sparse b: the expected
+    coefficients are a few shifted, scaled copies of a, computed on the device in 64-bit integers."""
+    L, n = 1 << log_len, 1 << (log_len - 1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77 + log_len)
+    a = torch.zeros(L, dtype=torch.int64, device="cuda")
+    a[:n] = torch.randint(0, p, (n,), generator=g, device="cuda", dtype=torch.int64)
+    terms = {0: 3, 1: 1, 12345: 77, n // 2 + 5: 1000, n - 1: 2, (n // 3) | 1: 1}
+    if unit_terms:                       # moduli near 2^62: keep every intermediate below 2^63
+        terms = {k: 1 for k in terms}
+    b = torch.zeros(L, dtype=torch.int64, device="cuda")
+    want = torch.zeros(L, dtype=torch.int64, device="cuda")
+    for k, v in terms.items():
+        b[k] = v
+        want[k:k + n] = (want[k:k + n] + a[:n] * v % p) % p
+    c = torch.empty_like(a)
+    st = torch.cuda.current_stream().cuda_stream
+    for x, y in ((a, b), (b, a)):
+        nttx.dev_direct_multiply_u64(x.data_ptr(), y.data_ptr(), c.data_ptr(), n, p, 1, st)
+        torch.cuda.synchronize()
+        assert torch.equal(c[: 2 * n - 1], want[: 2 * n - 1])
+
+
+@pytest.mark.parametrize("name,log_len,passes", [("lazy_lo1", 20, 2), ("lazy_lo1", 21, 2), ("lazy_lo1", 22, 3), ("lazy", 22, 2),
+                                                 ("safe_lo1", 21, 2), ("safe", 22, 2), ("lazy_lo1", 23, 3), ("safe_lo1", 24, 3)])
+def test_long_lengths_sparse_factor(nttx, name, log_len, passes):
+    """Two-pass plans around rows of 2^11 .. 2^13 points (2^20 .. 2^22) and three-pass plans beyond, every
+    reduction class.  A 51-bit modulus of the lazy class leaves room for 12 unreduced forward stages, not
+    13, so its 2^22 plan keeps three passes."""
+    p = PRIMES[name]
+    assert len(nttx.plan_info_u64(1 << log_len, p)) == passes
+    _sparse_check(nttx, p, log_len, unit_terms=name.startswith("safe"))
+
+
 def test_three_pass_length(nttx, oracle):
-    """Product length 2^21 (three passes on 64-bit lanes) against the library's CRT route, the
+    """Product length 2^21 against the library's CRT route, the
     longest length that route supports, on a 40-bit modulus (n p^2 must stay below the CRT bound);
     the id 4 modulus at the same length by evaluation."""
     p, n = 1099469684737, 1 << 20              # 262134 * 2^22 + 1
