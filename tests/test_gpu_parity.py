@@ -469,3 +469,37 @@ def test_fuzz_multi_pass_lengths(nttx, oracle):
             want = oracle.poly_multiply_crt(a, b, p)
             got = nttx.poly_multiply(a, b, n, p, dtype=np.uint64)
             assert np.array_equal(got, want), (p, n, k)
+
+
+def test_device_call_is_graph_capturable(nttx, oracle):
+    """After nttx_reserve and one warm-up call (plans and workspace exist), the device-resident product makes no
+    allocation and no synchronising call, so a caller can capture it in a HIP graph; replays give the eager result."""
+    import torch
+    p, L, batch = 469762049, 1 << 16, 4
+    n = L // 2
+    a = torch.zeros((batch, L), dtype=torch.int32, device="cuda")
+    b = torch.zeros_like(a)
+    a[:, :n] = torch.from_numpy(rand(oracle, n * batch, 81, p).astype(np.int64).reshape(batch, n)).cuda().to(torch.int32)
+    b[:, :n] = torch.from_numpy(rand(oracle, n * batch, 82, p).astype(np.int64).reshape(batch, n)).cuda().to(torch.int32)
+    eager, replayed = torch.empty_like(a), torch.zeros_like(a)
+    nttx.reserve(L, batch, 1)
+    nttx.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), eager.data_ptr(), n, p, batch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        nttx.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), replayed.data_ptr(), n, p, batch, side.cuda_stream)
+        torch.cuda.synchronize()
+        replayed.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for i in range(batch):     # one launch group per product, as a latency-bound caller would issue them
+                nttx.dev_poly_multiply_u32(a[i].data_ptr(), b[i].data_ptr(), replayed[i].data_ptr(), n, p, 1,
+                                           torch.cuda.current_stream().cuda_stream)
+    assert int(replayed.abs().max()) == 0          # capture records, it does not run
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(replayed, eager)
+    want = oracle.ntt_compute(a[1].cpu().numpy().view(np.uint32), b[1].cpu().numpy().view(np.uint32), p)
+    assert np.array_equal(replayed[1].cpu().numpy().view(np.uint32), want)
