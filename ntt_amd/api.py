@@ -50,6 +50,7 @@ _SIGS = [
     ("nttx_profile_reset", C.c_int, []),
     ("nttx_profile_read", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     ("nttx_plan_info", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    ("nttx_dev_negacyclic_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_plan_info_u64", C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_int)]),
 ]
 
@@ -237,6 +238,11 @@ def crt_prime(k: int) -> int:
     v = C.c_uint32(0)
     _check(lib().nttx_crt_prime(k, C.byref(v)))
     return v.value
+
+
+def dev_negacyclic_multiply_u64(d_a: int, d_b: int, d_c: int, length: int, p: int, batch: int, stream: int = 0):
+    """c = a*b mod (x^length + 1, p) on [batch][length] u64 device arrays (64-bit lanes, 2^31 <= p < 2^62)."""
+    _check(lib().nttx_dev_negacyclic_multiply_u64(d_a, d_b, d_c, length, p, batch, stream))
 
 
 def crt_primes_for(p: int, n: int):

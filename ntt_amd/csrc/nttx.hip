@@ -1128,6 +1128,15 @@ int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t
   return 0;
 }
 
+int nttx_dev_negacyclic_multiply_u64(const void *d_a, const void *d_b, void *d_c, int len, uint64_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_c || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments (len must be a power of two >= 2)");
+  int k = 0; while ((1 << k) < len) ++k;
+  const ProfHook64 ph = prof_hook(cx);
+  return fail_from64(engine64_negacyclic_multiply(cx->e64, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint64_t *)d_c, k, p, batch,
+                                                  (hipStream_t)stream, &ph));
+}
+
 int nttx_dev_direct_multiply_u64(const void *d_a, const void *d_b, void *d_c, int n, uint64_t p, int batch, void *stream) {
   NTTX_ENTER();
   if (!d_a || !d_b || !d_c || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");

@@ -82,9 +82,17 @@ struct Buf64 {
   ~Buf64() { if (ptr) (void)hipFree(ptr); }
 };
 
+// psi^i and psi^-i, i < 2^logL, Montgomery form: psi a primitive 2^(logL+1)-th root of unity
+struct Twist64 {
+  uint64_t *fwd = nullptr, *inv = nullptr;
+  ~Twist64() { if (fwd) (void)hipFree(fwd); if (inv) (void)hipFree(inv); }
+};
+
 struct Engine64 {
   std::map<std::tuple<uint64_t, int, bool>, std::unique_ptr<Plan64>> plans;
+  std::map<std::pair<uint64_t, int>, std::unique_ptr<Twist64>> twists;
   Buf64 wa, wb;
+  Buf64 ta, tb;      // twisted copies of the inputs of a negacyclic product
 };
 
 Engine64 *engine64_create() { return new Engine64; }
@@ -297,6 +305,62 @@ int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, 
   return 0;
 }
 
+static dim3 ew_grid64(long long per_vec, int batch, int z) {
+  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
+}
+
+static int get_twist64(Engine64 *e, Plan64 *pl, Twist64 **out) {
+  auto key = std::make_pair(pl->p, pl->logL);
+  auto it = e->twists.find(key);
+  if (it != e->twists.end()) { *out = it->second.get(); return 0; }
+  const uint64_t p = pl->p;
+  const int logL = pl->logL;
+  if (logL + 1 > kMaxLog64 || ((p - 1) & ((2ull << logL) - 1)) != 0)
+    return fail64(NTTX_EINVAL, "modulus %llu has no 2^%d-th root of unity for a negacyclic product of length 2^%d",
+                  (unsigned long long)p, logL + 1, logL);
+  const HostMont64 M{p, pl->ctx.npinv, pl->ctx.one, pl->ctx.r2};
+  const uint64_t g = find_nonresidue64(p);
+  const uint64_t psi = h_powmod64(g, (p - 1) >> (logL + 1), p), psii = h_powmod64(psi, p - 2, p);
+  const size_t len = (size_t)1 << logL;
+  std::vector<uint64_t> f(len), b(len);
+  const uint64_t sf = M.to(psi), sb = M.to(psii);
+  uint64_t cf = M.one, cb = M.one;
+  for (size_t i = 0; i < len; ++i) { f[i] = cf; b[i] = cb; cf = M.mul(cf, sf); cb = M.mul(cb, sb); }
+  std::unique_ptr<Twist64> tw(new Twist64);
+  if (int rc = upload64(&tw->fwd, f)) return rc;
+  if (int rc = upload64(&tw->inv, b)) return rc;
+  *out = tw.get();
+  e->twists[key] = std::move(tw);
+  return 0;
+}
+
+// c = a b mod (x^len + 1, p): a and b times psi^i, cyclic product, times psi^-i (element-wise passes around the product)
+int engine64_negacyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
+                                 int batch, hipStream_t st, const ProfHook64 *prof) {
+  Plan64 *pl; Twist64 *tw;
+  if (logL < 1) return fail64(NTTX_EINVAL, "length must be at least 2");
+  if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
+  if (int rc = get_twist64(e, pl, &tw)) return rc;
+  const size_t vec = ((size_t)batch << logL) * 8;
+  if (int rc = e->ta.ensure(vec)) return rc;
+  if (int rc = e->tb.ensure(vec)) return rc;
+  uint64_t *ta = (uint64_t *)e->ta.ptr, *tb = (uint64_t *)e->tb.ptr;
+  Twist64Args T{}; T.src[0] = a; T.src[1] = b; T.dst[0] = ta; T.dst[1] = tb; T.tab = tw->fwd; T.ctx = pl->ctx; T.len = 1 << logL; T.canon = 0;
+  if (prof) prof->begin(prof->self, NTTX_K_MISC, st);
+  if (pl->plo1) hipLaunchKernelGGL((twist64_kernel<true>), ew_grid64(T.len / 2, batch, 2), dim3(256), 0, st, T);
+  else hipLaunchKernelGGL((twist64_kernel<false>), ew_grid64(T.len / 2, batch, 2), dim3(256), 0, st, T);
+  if (prof) prof->end(prof->self, st);
+  HIPCHK64(hipGetLastError());
+  if (int rc = engine64_cyclic_multiply(e, ta, tb, c, logL, p, batch, 0, st, prof)) return rc;
+  Twist64Args U{}; U.src[0] = c; U.dst[0] = c; U.tab = tw->inv; U.ctx = pl->ctx; U.len = 1 << logL; U.canon = 1;
+  if (prof) prof->begin(prof->self, NTTX_K_MISC, st);
+  if (pl->plo1) hipLaunchKernelGGL((twist64_kernel<true>), ew_grid64(U.len / 2, batch, 1), dim3(256), 0, st, U);
+  else hipLaunchKernelGGL((twist64_kernel<false>), ew_grid64(U.len / 2, batch, 1), dim3(256), 0, st, U);
+  if (prof) prof->end(prof->self, st);
+  HIPCHK64(hipGetLastError());
+  return 0;
+}
+
 int engine64_forward(Engine64 *e, uint64_t *x, int logL, uint64_t p, int inverse, int batch, hipStream_t st,
                      const ProfHook64 *prof) {
   Plan64 *pl;
@@ -314,9 +378,6 @@ int engine64_forward(Engine64 *e, uint64_t *x, int logL, uint64_t p, int inverse
   return launch_row64(pl, 0, pl->lt[ncol], R, st, prof);
 }
 
-static dim3 ew_grid64(long long per_vec, int batch, int z) {
-  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
-}
 
 int engine64_pad(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *pa, uint64_t *pb, int n, int logL,
                  uint64_t p, int batch, hipStream_t st) {

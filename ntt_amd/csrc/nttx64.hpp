@@ -30,6 +30,10 @@ int engine64_decompose(int logL, uint64_t p, int lt[3]);   // the pass sizes dep
 // canonical.  nvalid > 0: only the first nvalid words of each input vector are read.
 int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
                              int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof);
+// c = a b mod (x^len + 1, p), len = 2^logL, all [batch][len] u64 device arrays; inputs any 64-bit words, outputs
+// canonical; needs 2^(logL+1) | p-1
+int engine64_negacyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
+                                 int batch, hipStream_t st, const ProfHook64 *prof);
 // in-place transform, natural in -> bit-reversed out, root w or (inverse != 0) w^-1, no scaling
 int engine64_forward(Engine64 *e, uint64_t *x, int logL, uint64_t p, int inverse, int batch, hipStream_t st,
                      const ProfHook64 *prof);

@@ -533,6 +533,30 @@ __global__ void pad64_kernel(PadArgs64 A) {
   }
 }
 
+// dst[i] = src[i] * tab[i] (tab in Montgomery form): the psi^i / psi^-i factors of a negacyclic product.
+// Results are below 2p, or canonical when asked; any 64-bit input word is admissible.
+struct Twist64Args {
+  const uint64_t *src[2];
+  uint64_t *dst[2];
+  const uint64_t *tab;
+  PrimeArgs64 ctx;
+  int len, canon;
+};
+template <bool PLO1>
+__global__ void twist64_kernel(Twist64Args A) {
+  const long long b = blockIdx.y;
+  const uint64_t *src = A.src[blockIdx.z] + b * A.len;
+  uint64_t *dst = A.dst[blockIdx.z] + b * A.len;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2; i < A.len; i += gridDim.x * blockDim.x * 2) {
+    const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(src + i), f = *reinterpret_cast<const ulonglong2 *>(A.tab + i);
+    ulonglong2 y;
+    y.x = mont64_lazy<PLO1>(x.x, f.x, A.ctx.p, A.ctx.npinv);
+    y.y = mont64_lazy<PLO1>(x.y, f.y, A.ctx.p, A.ctx.npinv);
+    if (A.canon) { y.x = csub64(y.x, A.ctx.p); y.y = csub64(y.y, A.ctx.p); }
+    *reinterpret_cast<ulonglong2 *>(dst + i) = y;
+  }
+}
+
 __global__ void unpad64_kernel(const uint64_t *src, uint64_t *dst, int nout, int len) {
   const long long b = blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)

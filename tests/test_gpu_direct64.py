@@ -186,3 +186,31 @@ def test_errors(nttx):
     with pytest.raises(nttx.NttxError):
         nttx.poly_multiply_direct64(a, a, 8, 469762049)                  # 32-bit modulus: other path
     assert nttx.path_for((1 << 61) - 1, 8) == nttx.PATH_CRT4               # prime, but 2^4 does not divide p-1
+
+
+@pytest.mark.parametrize("name,log_len,batch", [("lazy_lo1", 1, 3), ("lazy_lo1", 5, 3), ("lazy_lo1", 10, 3), ("lazy_lo1", 12, 2),
+                                                ("lazy_lo1_top", 13, 2), ("lazy", 14, 2), ("lazy_small", 11, 2), ("safe_lo1", 12, 2),
+                                                ("safe", 13, 2), ("lazy_lo1", 16, 1)])
+def test_negacyclic_product_u64(nttx, oracle, name, log_len, batch):
+    """c = a b mod (x^len + 1, p) on 64-bit lanes: lin[i] - lin[i + len] of the linear product, which the library's
+    own direct route gives (itself pinned to the oracle above); for small lengths also the schoolbook product."""
+    p = PRIMES[name]
+    L = 1 << log_len
+    a = np.stack([rand(oracle, L, 500 + i, p) for i in range(batch)])
+    b = np.stack([rand(oracle, L, 600 + i, p) for i in range(batch)])
+    a[0, 0] += np.uint64(p)                                  # inputs need not be reduced
+    da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    dc = torch.empty_like(da)
+    nttx.dev_negacyclic_multiply_u64(da.data_ptr(), db.data_ptr(), dc.data_ptr(), L, p, batch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy().view(np.uint64)
+    a[0, 0] -= np.uint64(p)
+    for i in range(batch):
+        lin = (oracle.poly_multiply_naive_u64(a[i], b[i], p) if L <= 1024 else nttx.poly_multiply_direct64(a[i], b[i], L, p))
+        lin = np.concatenate([lin, np.zeros(1, np.uint64)])
+        lo, hi = lin[:L], lin[L:]
+        want = np.where(lo >= hi, lo - hi, lo + np.uint64(p) - hi)
+        assert np.array_equal(got[i], want), (name, log_len, i)
+    assert torch.equal(da.cpu(), torch.from_numpy((a + np.array([[p] + [0] * (L - 1)] + [[0] * L] * (batch - 1), dtype=np.uint64)).view(np.int64)))
+    with pytest.raises(nttx.NttxError):                      # 8191 * 2^20 + 1: no 2^21-th root
+        nttx.dev_negacyclic_multiply_u64(da.data_ptr(), db.data_ptr(), dc.data_ptr(), 1 << 20, PRIMES["lazy_small"], 1, 0)
