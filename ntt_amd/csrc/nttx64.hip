@@ -208,7 +208,9 @@ static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
     using Lyt = RowLayout64<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
     const int cap = K >= 12 ? (1 << 20) : cap_row;   /* long rows: one row per workgroup */ \
-    if constexpr (MODE == 2) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
+    if constexpr (MODE == 2) { \
+      if (A.psi_in) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
+      else hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); } \
     else hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
     break; }
   static const int cap_row = env_int64("NTTX_GRID_ROW64", 4096);
@@ -240,6 +242,7 @@ static int launch_col64_t(int logT, const ColArgs64 &A, int nvec, hipStream_t st
   static const int cap_col = env_int64("NTTX_GRID_COL64", 1 << 20);   // one tile per workgroup, as on the 32-bit path
   const int grid = grid_for64(tiles, std::max(1, cap_col / nvec));
 #define NTTX_COL64_CASE(K) case K: \
+    if constexpr (!ZHI) { if (A.psi) { hipLaunchKernelGGL((col64_kernel<K, INV, SAFE, PLO1, false, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break; } } \
     hipLaunchKernelGGL((col64_kernel<K, INV, SAFE, PLO1, ZHI>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
   switch (logT) {
     NTTX_COL64_CASE(6) NTTX_COL64_CASE(7) NTTX_COL64_CASE(8) NTTX_COL64_CASE(9)
@@ -269,14 +272,19 @@ int engine64_reserve(Engine64 *e, int logL, int batch) {
   return e->wb.ensure(vec);
 }
 
-int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
-                             int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof) {
+// psi_in / psi_out (one- and two-pass plans): the product becomes the negacyclic one, a and b multiplied by psi_in[i] as
+// the first pass reads them and c by psi_out[i] as the last pass writes it
+static int cyclic_multiply64(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
+                             int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof,
+                             const uint64_t *psi_in, const uint64_t *psi_out) {
   Plan64 *pl;
   if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
   const long long len = 1ll << logL;
+  if (psi_in && pl->npass > 2) return fail64(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
   if (pl->npass == 1) {
     RowArgs64 R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
     R.ctx = pl->ctx; R.pre = pl->pre_single; R.canon_out = 1; R.nrows = batch;
+    R.psi_in = psi_in; R.psi_out = psi_out;
     return launch_row64(pl, 2, pl->lt[0], R, st, prof);
   }
   if (int rc = engine64_reserve(e, logL, batch)) return rc;
@@ -288,6 +296,7 @@ int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, 
     C.tw = pl->tw_fwd[lv]; C.fs = pl->fs_fwd[lv]; C.ctx = pl->ctx; C.logS = logN - pl->lt[lv]; C.canon_out = 0;
     C.nblocks = ((long long)batch << logL) >> logN;
     C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
+    if (lv == 0 && psi_in) { C.psi = psi_in; C.nvalid = 0; }
     if (int rc = launch_col64(pl, false, pl->lt[lv], C, 2, st, prof)) return rc;
     logN = C.logS;
   }
@@ -300,9 +309,15 @@ int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, 
     int logNl = logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
     ColArgs64 C{}; C.in[0] = c; C.out[0] = c; C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx;
     C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0); C.nblocks = ((long long)batch << logL) >> logNl;
+    if (lv == 0 && psi_out) C.psi = psi_out;
     if (int rc = launch_col64(pl, true, pl->lt[lv], C, 1, st, prof)) return rc;
   }
   return 0;
+}
+
+int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
+                             int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof) {
+  return cyclic_multiply64(e, a, b, c, logL, p, batch, nvalid, st, prof, nullptr, nullptr);
 }
 
 static dim3 ew_grid64(long long per_vec, int batch, int z) {
@@ -334,13 +349,16 @@ static int get_twist64(Engine64 *e, Plan64 *pl, Twist64 **out) {
   return 0;
 }
 
-// c = a b mod (x^len + 1, p): a and b times psi^i, cyclic product, times psi^-i (element-wise passes around the product)
+// c = a b mod (x^len + 1, p): a and b times psi^i, cyclic product, times psi^-i
 int engine64_negacyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
                                  int batch, hipStream_t st, const ProfHook64 *prof) {
   Plan64 *pl; Twist64 *tw;
   if (logL < 1) return fail64(NTTX_EINVAL, "length must be at least 2");
   if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
   if (int rc = get_twist64(e, pl, &tw)) return rc;
+  // one- and two-pass plans apply psi^i inside their first and last pass; three-pass plans use element-wise passes
+  static const bool unfused = [] { const char *e_ = getenv("NTTX_TWIST_UNFUSED"); return e_ && atoi(e_) != 0; }();
+  if (pl->npass <= 2 && !unfused) return cyclic_multiply64(e, a, b, c, logL, p, batch, 0, st, prof, tw->fwd, tw->inv);
   const size_t vec = ((size_t)batch << logL) * 8;
   if (int rc = e->ta.ensure(vec)) return rc;
   if (int rc = e->tb.ensure(vec)) return rc;

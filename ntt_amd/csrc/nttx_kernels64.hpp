@@ -234,17 +234,27 @@ struct RowArgs64 {
   uint64_t pre;          // MODE 2: Montgomery constant applied to a before a*b: R^2 (times n^-1 on single-pass lengths)
   int canon_out;
   long long nrows;
+  // negacyclic products (TWIST kernels, rows = whole vectors): inputs times psi_in[i] on the way in, outputs times
+  // psi_out[i] on the way out (Montgomery form, T words each)
+  const uint64_t *psi_in, *psi_out;
 };
 
-template <class L>
-__device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long long row0, long long nrows) {
+template <class L, bool TW = false, class AR = void>
+__device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long long row0, long long nrows,
+                                           const uint64_t *psi = nullptr, const AR *M = nullptr) {
   constexpr int T = L::T;
   if constexpr (T >= 2) {
     constexpr int NV2 = L::NT * T / 2;
     for (int v = threadIdx.x; v < NV2; v += L::NTHR) {
       const int c = (v * 2) >> L::LOGT, j = (v * 2) & (T - 1);
       ulonglong2 x = make_ulonglong2(0, 0);
-      if (row0 + c < nrows) x = *reinterpret_cast<const ulonglong2 *>(in + (row0 + c) * T + j);
+      if (row0 + c < nrows) {
+        x = *reinterpret_cast<const ulonglong2 *>(in + (row0 + c) * T + j);
+        if constexpr (TW) {
+          const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(psi + j);
+          x.x = M->mul(x.x, f.x); x.y = M->mul(x.y, f.y);
+        }
+      }
       *reinterpret_cast<ulonglong2 *>(s + L::addr(c, j)) = x;
     }
   }
@@ -354,7 +364,8 @@ __device__ __forceinline__ void edge_round64(uint64_t *s, const uint64_t *tw, co
   }
 }
 
-template <int LOGT, bool SAFE, bool PLO1>
+// TWIST: negacyclic product of whole vectors (single pass, canonical output): psi factors on load and store.
+template <int LOGT, bool SAFE, bool PLO1, bool TWIST = false>
 __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1)) rowmul64_kernel(RowArgs64 A) {
   using L = RowLayout64<LOGT>;
   using AR = Arith64<SAFE, PLO1>;
@@ -371,12 +382,12 @@ __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1))
   for (long long row0 = (long long)blockIdx.x * L::NT; row0 < A.nrows; row0 += (long long)gridDim.x * L::NT) {
     uint64_t ra[8], rb[8];
     __syncthreads();
-    row_load64<L>(sa, A.in0, row0, A.nrows);
+    row_load64<L, TWIST, AR>(sa, A.in0, row0, A.nrows, A.psi_in, &M);
     __syncthreads();
     dif_head64<L, LOGT, AR, TWL>(sa, A.tw_fwd, twf, M);
     edge_round64<L, RL, false, true, false, AR>(sa, twf, M, ra);
     __syncthreads();
-    row_load64<L>(sa, A.in1, row0, A.nrows);
+    row_load64<L, TWIST, AR>(sa, A.in1, row0, A.nrows, A.psi_in, &M);
     __syncthreads();
     dif_head64<L, LOGT, AR, TWL>(sa, A.tw_fwd, twf, M);
     edge_round64<L, RL, false, true, false, AR>(sa, twf, M, rb);
@@ -396,7 +407,10 @@ __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1))
       const int c = (v * 2) >> LOGT, j = (v * 2) & (T - 1);
       if (row0 + c < A.nrows) {
         ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(sa + L::addr(c, j));
-        if (A.canon_out) { x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one); }
+        if constexpr (TWIST) {     // the multiplication is also the reduction: below 2p, then canonical
+          const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi_out + j);
+          x.x = csub64(M.mul(x.x, f.x), M.p); x.y = csub64(M.mul(x.y, f.y), M.p);
+        } else if (A.canon_out) { x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one); }
         *reinterpret_cast<ulonglong2 *>(A.out + (row0 + c) * T + j) = x;
       }
     }
@@ -419,10 +433,14 @@ struct ColArgs64 {
   int canon_out;
   long long nblocks;
   long long nvalid;
+  const uint64_t *psi;   // TWIST kernels (outermost pass of a negacyclic product): psi^i forward, psi^-i inverse, N words
 };
 
-template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI>
+// TWIST: outermost pass of a negacyclic product: forward inputs times psi^i as they are read, inverse outputs times
+// psi^-i before the canonical store.
+template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI, bool TWIST = false>
 __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
+  static_assert(!TWIST || !ZHI, "twisted passes read whole vectors");
   constexpr int LOGC = 4, NTHR = 512;
   using L = ColLayout64<LOGT, LOGC, NTHR>;
   using AR = Arith64<SAFE, PLO1>;
@@ -482,6 +500,9 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
       if (INV) {
         const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
         x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
+      } else if constexpr (TWIST) {
+        const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi + fbase + ((long long)j << logS) + c2);
+        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
       }
       *reinterpret_cast<ulonglong2 *>(s + L::addr(c2, j)) = x;
     }
@@ -503,6 +524,9 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
         const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
         x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
         if (A.canon_out) { x.x = csub64(x.x, M.p); x.y = csub64(x.y, M.p); }
+      } else if constexpr (TWIST) {
+        const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi + fbase + ((long long)j << logS) + c2);
+        x.x = csub64(M.mul(x.x, f.x), M.p); x.y = csub64(M.mul(x.y, f.y), M.p);
       } else if (A.canon_out) {
         x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one);
       }

@@ -190,10 +190,12 @@ def test_errors(nttx):
 
 @pytest.mark.parametrize("name,log_len,batch", [("lazy_lo1", 1, 3), ("lazy_lo1", 5, 3), ("lazy_lo1", 10, 3), ("lazy_lo1", 12, 2),
                                                 ("lazy_lo1_top", 13, 2), ("lazy", 14, 2), ("lazy_small", 11, 2), ("safe_lo1", 12, 2),
-                                                ("safe", 13, 2), ("lazy_lo1", 16, 1)])
+                                                ("safe", 13, 2), ("lazy_lo1", 16, 1), ("safe_lo1", 17, 1), ("lazy_lo1", 21, 1),
+                                                ("lazy_lo1", 23, 1)])
 def test_negacyclic_product_u64(nttx, oracle, name, log_len, batch):
     """c = a b mod (x^len + 1, p) on 64-bit lanes: lin[i] - lin[i + len] of the linear product, which the library's
-    own direct route gives (itself pinned to the oracle above); for small lengths also the schoolbook product."""
+    own direct route gives (itself pinned to the oracle above); for small lengths the schoolbook product.  One-pass
+    and two-pass plans apply the psi factors inside their kernels, the three-pass length (2^23) in separate passes."""
     p = PRIMES[name]
     L = 1 << log_len
     a = np.stack([rand(oracle, L, 500 + i, p) for i in range(batch)])
