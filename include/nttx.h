@@ -110,12 +110,14 @@ int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int 
 
 /* Negacyclic product on 64-bit lanes: d_c[b] = d_a[b] * d_b[b] mod (x^len + 1, p) on [batch][len] u64 device arrays
  * for an NTT-friendly prime 2^31 <= p < 2^62 with 2*len | p-1 (the ring of lattice-based schemes; no counterpart in
- * the reference, whose products are linear: the psi^i factors are applied in element-wise passes around the cyclic
- * product of nttx_dev_direct_multiply_u64).  Inputs: any 64-bit words; outputs canonical. */
+ * the reference, whose products are linear).  One- and two-pass lengths apply the psi^i factors inside their first
+ * and last pass, longer ones in element-wise passes around the cyclic product.  Inputs: any 64-bit words; outputs
+ * canonical. */
 int nttx_dev_negacyclic_multiply_u64(const void *d_a, const void *d_b, void *d_c, int len, uint64_t p, int batch, void *stream);
 
 /* 64-bit-lane counterpart of nttx_dev_poly_multiply_u32: d_a, d_b, d_c are zero-padded
- * [batch][len] u64 arrays, len the smallest power of two >= 2n; inputs below p. */
+ * [batch][len] u64 arrays, len the smallest power of two >= 2n (NOT [batch][n]: every array holds batch*len words);
+ * inputs below p. */
 int nttx_dev_direct_multiply_u64(const void *d_a, const void *d_b, void *d_c, int n, uint64_t p, int batch,
                                  void *stream);
 
