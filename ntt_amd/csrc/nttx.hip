@@ -23,6 +23,7 @@
 #include "nttx_arith.hpp"
 #include "nttx_kernels.hpp"
 #include "nttx64.hpp"
+#include "nttx_launch.hpp"
 
 namespace nttx {
 
@@ -347,70 +348,11 @@ static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream
   return launch_row_m<ROW_MUL>(h, logT, A, st);
 }
 
-// Column tile shape: 32 columns (full 128-byte lines) with 512 threads where the tile fits LDS
-// comfortably, 16 columns with 256 threads for the longest column passes.
-template <bool INV, int H, bool ZHI, bool FS2>
-static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
-  const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
-  // workgroups per launch (tuning knobs; any value is correct, workgroups stride over the tiles)
-  // Measured on MI355X: one tile per workgroup (the hardware dispatcher refills CUs as workgroups retire,
-  // which staggers their load / butterfly / store phases) beats a resident grid striding over the tiles
-  // by 12 % on the forward and 8 % on the inverse pass.
-  static const int capf = env_int("NTTX_GRID_COL", 1 << 20), capi = env_int("NTTX_GRID_COLI", 1 << 20);
-  const int cap = std::max(1, (INV ? capi : capf) / nvec);
-  const int g16 = (grid_for(tiles, cap) + 15) / 16 * 16;
-  const int grid = g16 <= tiles ? g16 : grid_for(tiles, cap);
-#define NTTX_COL_CASE(K, LC, NT) \
-    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, FS2>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
-  if constexpr (!FS2 && !ZHI) {
-    if (A.psi) {   // outermost pass of a negacyclic product (full 128-byte tiles only: the caller checks)
-#define NTTX_COLT_CASE(K, NT) \
-      hipLaunchKernelGGL((col_kernel<K, INV, H, 5, NT, false, false, true>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
-      switch (wide ? logT : 0) {
-        case 6: NTTX_COLT_CASE(6, 256)  case 7: NTTX_COLT_CASE(7, 256)  case 8: NTTX_COLT_CASE(8, 256)  case 9: NTTX_COLT_CASE(9, 1024)
-        default: return fail(NTTX_ERANGE, "twisted column pass of 2^%d points unsupported", logT);
-      }
-#undef NTTX_COLT_CASE
-      HIPCHK(hipGetLastError());
-      return 0;
-    }
-  }
-  if constexpr (FS2) {
-    switch (logT * 2 + wide) {
-      case 15: NTTX_COL_CASE(7, 5, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
-      case 19: NTTX_COL_CASE(9, 5, 512)   case 20: NTTX_COL_CASE(10, 4, 256)   // 512 threads: the 1024-thread shape has no registers left for the second factor
-      default: return fail(NTTX_ERANGE, "split-table column pass of 2^%d points unsupported", logT);
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
-  switch (logT * 2 + wide) {
-    case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
-    case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
-    case 16: NTTX_COL_CASE(8, 4, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
-    case 18: NTTX_COL_CASE(9, 4, 256)   case 19: NTTX_COL_CASE(9, 5, 1024)
-    case 20: NTTX_COL_CASE(10, 4, 256)
-    default: return fail(NTTX_ERANGE, "column pass of 2^%d points unsupported", logT);
-  }
-#undef NTTX_COL_CASE
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-template <bool INV, bool ZHI>
-static int launch_col_i(int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  if (A.fsa)
-    return h == 9 ? launch_col_t<INV, 9, ZHI, true>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4, ZHI, true>(logT, A, nvec, st)
-                                                                                : launch_col_t<INV, 2, ZHI, true>(logT, A, nvec, st);
-  return h == 9 ? launch_col_t<INV, 9, ZHI, false>(logT, A, nvec, st) : h == 4 ? launch_col_t<INV, 4, ZHI, false>(logT, A, nvec, st)
-                                                                               : launch_col_t<INV, 2, ZHI, false>(logT, A, nvec, st);
-}
-// A.nvalid > 0 selects the zero-padded-half forward variant (needs nvalid <= N/2)
+// column passes are compiled in their own translation unit (nttx_col.hip)
 static int launch_col_raw(bool inv, int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  if (logT < kMinColLog || A.logS < 4) return fail(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
-  if (inv) return launch_col_i<true, false>(h, logT, A, nvec, st);
-  if (A.nvalid > 0) return launch_col_i<false, true>(h, logT, A, nvec, st);
-  return launch_col_i<false, false>(h, logT, A, nvec, st);
+  const char *msg = nullptr;
+  const int rc = launch_col_kernels(inv, h, logT, A, nvec, st, &msg);
+  return rc ? fail(rc, "%s (logT=%d logS=%d)", msg ? msg : "column pass failed", logT, A.logS) : 0;
 }
 
 static int launch_row(Context *cx, int mode, int h, int logT, const RowArgs &A, hipStream_t st) {

@@ -16,6 +16,7 @@
 
 #include "../../include/nttx.h"
 #include "nttx64.hpp"
+#include "nttx64_launch.hpp"
 #include "nttx_arith.hpp"
 #include "nttx_kernels64.hpp"
 
@@ -236,33 +237,14 @@ static int launch_row64(const Plan64 *pl, int mode, int logT, const RowArgs64 &A
   return rc;
 }
 
-template <bool INV, bool SAFE, bool PLO1, bool ZHI>
-static int launch_col64_t(int logT, const ColArgs64 &A, int nvec, hipStream_t st) {
-  const long long tiles = A.nblocks << (A.logS - 4);
-  static const int cap_col = env_int64("NTTX_GRID_COL64", 1 << 20);   // one tile per workgroup, as on the 32-bit path
-  const int grid = grid_for64(tiles, std::max(1, cap_col / nvec));
-#define NTTX_COL64_CASE(K) case K: \
-    if constexpr (!ZHI) { if (A.psi) { hipLaunchKernelGGL((col64_kernel<K, INV, SAFE, PLO1, false, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break; } } \
-    hipLaunchKernelGGL((col64_kernel<K, INV, SAFE, PLO1, ZHI>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
-  switch (logT) {
-    NTTX_COL64_CASE(6) NTTX_COL64_CASE(7) NTTX_COL64_CASE(8) NTTX_COL64_CASE(9)
-    default: return fail64(NTTX_ERANGE, "column pass of 2^%d points unsupported", logT);
-  }
-#undef NTTX_COL64_CASE
-  HIPCHK64(hipGetLastError());
-  return 0;
-}
-template <bool INV, bool ZHI>
-static int launch_col64_c(const Plan64 *pl, int logT, const ColArgs64 &A, int nvec, hipStream_t st) {
-  if (pl->safe) return pl->plo1 ? launch_col64_t<INV, true, true, ZHI>(logT, A, nvec, st) : launch_col64_t<INV, true, false, ZHI>(logT, A, nvec, st);
-  return pl->plo1 ? launch_col64_t<INV, false, true, ZHI>(logT, A, nvec, st) : launch_col64_t<INV, false, false, ZHI>(logT, A, nvec, st);
-}
+// column passes are compiled in their own translation unit (nttx64_col.hip)
 static int launch_col64(const Plan64 *pl, bool inv, int logT, const ColArgs64 &A, int nvec, hipStream_t st, const ProfHook64 *prof) {
   if (logT < kMinCol64 || logT > kMaxCol64 || A.logS < 4) return fail64(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
   if (prof) prof->begin(prof->self, inv ? NTTX_K_COL_INV : NTTX_K_COL_FWD, st);
-  const int rc = inv ? launch_col64_c<true, false>(pl, logT, A, nvec, st)
-                     : (A.nvalid > 0 ? launch_col64_c<false, true>(pl, logT, A, nvec, st) : launch_col64_c<false, false>(pl, logT, A, nvec, st));
+  const char *msg = nullptr;
+  int rc = launch_col64_kernels(inv, pl->safe, pl->plo1, logT, A, nvec, st, &msg);
   if (prof) prof->end(prof->self, st);
+  if (rc) rc = fail64(rc, "%s (logT=%d logS=%d)", msg ? msg : "column pass failed", logT, A.logS);
   return rc;
 }
 

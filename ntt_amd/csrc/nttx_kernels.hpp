@@ -1069,7 +1069,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
 
 // out[i] = in[bitrev_logn(i)] within each length-2^logn vector (stand-alone transform API:
 // the reference's transform is natural-order in and out, main.cc:146-152).
-__global__ void bitrev_kernel(const uint32_t *in, uint32_t *out, int logn, long long total) {
+static __global__ void bitrev_kernel(const uint32_t *in, uint32_t *out, int logn, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long vec = i >> logn;
     const uint32_t k = (uint32_t)(i & ((1ll << logn) - 1));
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ uint32_t split_one(uint64_t x, const PrimeCtx &c) {
   const uint32_t l = csub(mont_mul_lazy((uint32_t)x, c.one, c.p, c.npinv), c.p);          // lo mod m
   return csub(h + l, c.p);
 }
-__global__ void split_kernel(SplitArgs A) {
+static __global__ void split_kernel(SplitArgs A) {
   const long long b = blockIdx.y;
   const uint64_t *src = A.src[blockIdx.z] + b * A.n;
   if (A.vec) {   // rows are 16-byte aligned: four coefficients per thread, 16-byte accesses
@@ -1133,7 +1133,7 @@ struct PadArgs {
   PrimeCtx ctx;
   int n, len, zfill;
 };
-__global__ void pad_kernel(PadArgs A) {
+static __global__ void pad_kernel(PadArgs A) {
   const long long b = blockIdx.y;
   const uint32_t *src = A.src[blockIdx.z] + b * A.n;
   uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
@@ -1153,7 +1153,7 @@ struct TwistArgs {
   PrimeCtx ctx;
   int len;
 };
-__global__ void twist_kernel(TwistArgs A) {
+static __global__ void twist_kernel(TwistArgs A) {
   const long long b = blockIdx.y;
   const uint32_t *src = A.src[blockIdx.z] + b * A.len;
   uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
@@ -1226,7 +1226,7 @@ __device__ __forceinline__ uint64_t crt_one(const CrtArgs &A, const uint32_t (&r
   return r;
 }
 // four consecutive indices per thread (16-byte residue loads) when the rows allow it
-__global__ void crt_kernel(CrtArgs A) {
+static __global__ void crt_kernel(CrtArgs A) {
   const long long b = blockIdx.y;
   uint64_t *out = A.out + b * A.nout;
   if (A.vec) {

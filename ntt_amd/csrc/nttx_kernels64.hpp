@@ -581,7 +581,7 @@ __global__ void twist64_kernel(Twist64Args A) {
   }
 }
 
-__global__ void unpad64_kernel(const uint64_t *src, uint64_t *dst, int nout, int len) {
+static __global__ void unpad64_kernel(const uint64_t *src, uint64_t *dst, int nout, int len) {
   const long long b = blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
     dst[b * nout + j] = src[b * len + j];
