@@ -93,3 +93,26 @@ def test_big_modulus_products_full_size(nttx, oracle):
     for i in (0, batch - 1):
         want = oracle.poly_multiply_crt(a[i].cpu().numpy().view(np.uint64), b[i].cpu().numpy().view(np.uint64), p)
         assert np.array_equal(c_crt[i].cpu().numpy().view(np.uint64), want), i
+
+
+@pytest.mark.parametrize("p,log_len", [(469762049, 21), (469762049, 22), (998244353, 23), (469762049, 24)])
+def test_long_transform_roundtrip_and_oracle(nttx, oracle, p, log_len):
+    """Single transforms at two-pass (long rows) and three-pass lengths through the transform API: forward then
+    inverse is len * x, the forward transform of a sparse vector matches its defining sum at sampled outputs, and
+    at 2^21 the whole output equals ntt_iter_barrett."""
+    L = 1 << log_len
+    x = oracle.fill_random(L, 90 + log_len, p).astype(np.uint32)
+    fx = nttx.ntt(x, p, False)
+    back = nttx.ntt(fx, p, True)
+    assert np.array_equal(back.astype(np.uint64), x.astype(np.uint64) * np.uint64(L % p) % np.uint64(p))
+    if log_len == 21:
+        assert np.array_equal(fx, oracle.ntt_iter_barrett(x, p, False))
+    sp = np.zeros(L, np.uint32)
+    terms = {0: 5, 3: 7, L // 2 + 1: 11, L - 1: 13}
+    for k, v in terms.items():
+        sp[k] = v
+    fs = nttx.ntt(sp, p, False)
+    w = pow(3, (p - 1) // L, p)                      # main.cc:156
+    for out in (0, 1, 2, L // 3, L - 1):
+        want = sum(v * pow(w, (k * out) % L, p) for k, v in terms.items()) % p
+        assert int(fs[out]) == want, (log_len, out)
