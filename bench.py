@@ -125,7 +125,19 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL carries only the barrier and the max of the elapsed time here (the data path has no collective);
+            # if it cannot come up on this node, the same two calls run over gloo on host memory
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:                       # noqa: BLE001
+                sys.stderr.write(f"rank {rank}: RCCL unavailable ({exc}); control-plane collectives over gloo\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                rehearsal = True                           # reductions on host tensors from here on
     ntt_amd.init(device_index)
 
     L, n, B = 1 << LOG_L, 1 << (LOG_L - 1), args.batch
