@@ -110,8 +110,10 @@ static int decompose(int k, int lt[3]) {
   if (k <= kMaxRowLog) { lt[0] = k; return 1; }
   if (k <= kMaxLongRow && (longrow_mode() & 2)) { lt[0] = k; return 1; }
   if (k <= 9 + kMaxRowLog) {
-    // 2^9-point column passes run on full 128-byte tiles; 2^10-point ones only on 64-byte tiles
-    lt[0] = std::min(9, k / 2);
+    // 2^9-point column passes run on full 128-byte tiles (2^10-point ones only on 64-byte tiles), and the
+    // 512-point row pass is the wave-per-row kernel: lengths 2^15 .. 2^18 put 9 stages in the row pass
+    // (2 % faster at 2^15 and 2^16 than an even split), longer ones in the column pass
+    lt[0] = (k <= 18) ? std::max(kMinColLog, k - 9) : 9;
     lt[1] = k - lt[0];
     return 2;
   }

@@ -118,7 +118,7 @@ def test_plan_decomposition():
     assert ntt_amd.plan_info(1 << 11) == [11]
     assert ntt_amd.plan_info(1 << 12) == [12]               # one workgroup per row up to 2^14 points
     assert ntt_amd.plan_info(1 << 14) == [14]
-    assert ntt_amd.plan_info(1 << 15) == [7, 8]
+    assert ntt_amd.plan_info(1 << 15) == [6, 9] and ntt_amd.plan_info(1 << 16) == [7, 9]
     assert ntt_amd.plan_info(1 << 18) == [9, 9]
     assert ntt_amd.plan_info(1 << 20) == [9, 11]
     assert ntt_amd.plan_info(1 << 21) == [9, 12]
