@@ -60,6 +60,14 @@ def cpu_baseline(n, p, reps=3):
     med = statistics.median(ms)
     out = {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "sample": what,
            "ms_per_mult": med, "note": "the reference's NTT stage uses at most 4 threads (one per CRT prime, main.cc:306)"}
+    if po.have_ref():     # the pthread twin of the same four-prime program (main_pthread.cc: 4 NTT threads + CRT threads)
+        try:
+            _, lat2, _ = po.run_ref_main(cases, which="ref_main_pthread", reps=reps)
+            ms2 = [x for k in (1, 2, 3, 4) for x in lat2.get(k, [])]
+            if ms2:
+                out["main_pthread_ms_per_mult"] = statistics.median(ms2)
+        except Exception:                                  # noqa: BLE001  (a reported extra, never fatal)
+            pass
     # the reference's single-prime programs on the same workload (the CPU analogue of the GPU path):
     # get_result_pthread (pthread_normal.cpp:361-413, 8 threads, Montgomery R = 2^30, conversions to and
     # from Montgomery form included) and one ntt_compute_omp call (main.cc:185-209, Barrett, one thread)
