@@ -793,7 +793,7 @@ int nttx_plan_info_u64(int len, uint64_t p, int *logt) {
   if (len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two >= 2");
   int k = 0; while ((1 << k) < len) ++k;
   int lt[3] = {0, 0, 0};
-  const int np = engine64_decompose(k, p, lt);
+  const int np = engine64_decompose(k, p, lt, engine64_fp_ok(p));
   if (logt) for (int i = 0; i < np; ++i) logt[i] = lt[i];
   return np;
 }

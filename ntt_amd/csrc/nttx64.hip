@@ -13,6 +13,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <cstring>
 
 #include "../../include/nttx.h"
 #include "nttx64.hpp"
@@ -37,15 +38,22 @@ constexpr int kMaxRow64 = 13, kMinCol64 = 6, kMaxCol64 = 9, kMaxLog64 = 29;
 // Longest row pass for modulus p.  Rows of 2^12 and 2^13 points take one whole workgroup each
 // (NTTX_LONGROW64=0: the plans without them, for A/B runs).  In the lazy class (p < 2^51) a forward
 // pass of k stages on values below 2p ends below 2^(k+1) p, which has to fit 64 bits: k <= 63 - bits(p).
-static int max_row64(uint64_t p) {
+// Moduli of the floating-point class (nttx_kernels64.hpp: ArithFP): 2^31 <= p < 1.35e15, where three and a
+// quarter multiples of p stay below 2^52.  NTTX_FP64=0 switches the class off (A/B runs).
+bool engine64_fp_ok(uint64_t p) {
+  static const bool off = [] { const char *e = getenv("NTTX_FP64"); return e && atoi(e) == 0; }();
+  return !off && p >= (1ull << 31) && p < 1350000000000000ull;
+}
+
+static int max_row64(uint64_t p, bool fp) {
   static const int m = [] { const char *e = getenv("NTTX_LONGROW64"); return (e && atoi(e) == 0) ? 11 : kMaxRow64; }();
-  if (p >= (1ull << 51)) return m;                       // Harvey butterflies: values never leave [0, 2p)
+  if (fp || p >= (1ull << 51)) return m;                 // values never grow: floating-point class, Harvey butterflies
   int bits = 0; while (bits < 64 && (p >> bits)) ++bits;   // p < 2^bits
   return std::max(11, std::min(m, 63 - bits));
 }
 
-int engine64_decompose(int k, uint64_t p, int lt[3]) {
-  const int maxrow = max_row64(p);
+int engine64_decompose(int k, uint64_t p, int lt[3], bool fp) {
+  const int maxrow = max_row64(p, fp);
   if (k <= maxrow) { lt[0] = k; return 1; }
   if (k <= kMaxCol64 + maxrow) { lt[0] = std::min(kMaxCol64, k / 2); lt[1] = k - lt[0]; return 2; }
   int row = std::max((k + 2) / 3, k - 2 * kMaxCol64);
@@ -57,6 +65,8 @@ int engine64_decompose(int k, uint64_t p, int lt[3]) {
 
 struct Plan64 {
   uint64_t p = 0; int logL = 0; bool conj = false; bool safe = false, plo1 = false;
+  bool fp = false;            // floating-point class: tables hold (w, w/p) pairs of doubles, no Montgomery form
+  uint64_t pre_q = 0;         // fp: n^-1 / p as a double (pre_single holds n^-1 as a double)
   PrimeArgs64 ctx{};
   int npass = 0; int lt[3] = {0, 0, 0};
   uint64_t *tw_fwd[3] = {nullptr, nullptr, nullptr}, *tw_inv[3] = {nullptr, nullptr, nullptr};
@@ -90,7 +100,7 @@ struct Twist64 {
 };
 
 struct Engine64 {
-  std::map<std::tuple<uint64_t, int, bool>, std::unique_ptr<Plan64>> plans;
+  std::map<std::tuple<uint64_t, int, bool, bool>, std::unique_ptr<Plan64>> plans;
   std::map<std::pair<uint64_t, int>, std::unique_ptr<Twist64>> twists;
   Buf64 wa, wb;
   Buf64 ta, tb;      // twisted copies of the inputs of a negacyclic product
@@ -159,38 +169,88 @@ static int upload64(uint64_t **dst, const std::vector<uint64_t> &h) {
   return 0;
 }
 
-static int get_plan64(Engine64 *e, uint64_t p, int logL, bool conj, Plan64 **out) {
-  auto key = std::make_tuple(p, logL, conj);
+// (w, w/p) pairs of doubles for the floating-point class, from plain residues
+static uint64_t dbits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static std::vector<uint64_t> fp_pairs(const std::vector<uint64_t> &plain, uint64_t p) {
+  std::vector<uint64_t> out(2 * plain.size());
+  for (size_t i = 0; i < plain.size(); ++i) {
+    out[2 * i] = dbits((double)plain[i]);
+    out[2 * i + 1] = dbits((double)plain[i] / (double)p);
+  }
+  return out;
+}
+// plain-residue versions of the two table builders (the Montgomery "one" is 1 and products are ordinary)
+struct HostPlain64 {
+  uint64_t p;
+  uint64_t mul(uint64_t a, uint64_t b) const { return h_mulmod64(a, b, p); }
+};
+static std::vector<uint64_t> stage_table_plain(uint64_t w, int logT, uint64_t p) {
+  const int T = 1 << logT;
+  const HostPlain64 M{p};
+  std::vector<uint64_t> tab(std::max(T, 2), 0);
+  for (int h = 1; h < T; h <<= 1) {
+    const uint64_t step = h_powmod64(w, (uint64_t)(T / (2 * h)), p);
+    uint64_t cur = 1;
+    for (int j = 0; j < h; ++j) { tab[h + j] = cur; cur = M.mul(cur, step); }
+  }
+  return tab;
+}
+static std::vector<uint64_t> fourstep_table_plain(uint64_t wN, int logT, int logS, uint64_t extra, uint64_t p) {
+  const size_t T = (size_t)1 << logT, S = (size_t)1 << logS;
+  const HostPlain64 M{p};
+  std::vector<uint64_t> tab(T * S);
+  for (size_t j = 0; j < T; ++j) {
+    const uint64_t step = h_powmod64(wN, bitrev64((uint32_t)j, logT), p);
+    uint64_t cur = extra % p;
+    uint64_t *row = &tab[j * S];
+    for (size_t s = 0; s < S; ++s) { row[s] = cur; cur = M.mul(cur, step); }
+  }
+  return tab;
+}
+
+static int get_plan64(Engine64 *e, uint64_t p, int logL, bool conj, Plan64 **out, bool fp = false) {
+  auto key = std::make_tuple(p, logL, conj, fp);
   auto it = e->plans.find(key);
   if (it != e->plans.end()) { *out = it->second.get(); return 0; }
   if (!engine64_ok(p, logL))
     return fail64(NTTX_EINVAL, "modulus %llu does not support a direct 64-bit length-2^%d transform", (unsigned long long)p, logL);
   std::unique_ptr<Plan64> pl(new Plan64);
-  pl->p = p; pl->logL = logL; pl->conj = conj;
+  pl->p = p; pl->logL = logL; pl->conj = conj; pl->fp = fp;
   pl->safe = p >= (1ull << 51);
   pl->plo1 = (uint32_t)p == 1u;
   const PrimeCtx64 c = make_ctx64(p);
   HostMont64 M{p, c.npinv, (uint64_t)((((unsigned __int128)1) << 64) % p), c.r2};
   pl->ctx = PrimeArgs64{p, c.npinv, M.one, M.r2};
-  pl->npass = engine64_decompose(logL, p, pl->lt);
+  pl->npass = engine64_decompose(logL, p, pl->lt, fp);
   const uint64_t g = find_nonresidue64(p);
   uint64_t wL = h_powmod64(g, (p - 1) >> logL, p);                 // primitive 2^logL-th root (main.cc:156)
   if (conj) wL = h_powmod64(wL, p - 2, p);                         // main.cc:157
   const uint64_t wLi = h_powmod64(wL, p - 2, p);
   const uint64_t Lfull = 1ull << logL;
   const uint64_t ninv = h_powmod64(Lfull % p, p - 2, p);           // main.cc:204
-  pl->pre_single = M.mul(M.to(ninv), M.r2);                        // n^-1 R^2 mod p
+  if (fp) { pl->pre_single = dbits((double)ninv); pl->pre_q = dbits((double)ninv / (double)p); }
+  else pl->pre_single = M.mul(M.to(ninv), M.r2);                   // n^-1 R^2 mod p
   int logN = logL;
   for (int lv = 0; lv < pl->npass; ++lv) {
     const int lt = pl->lt[lv];
     const uint64_t wN = h_powmod64(wL, Lfull >> logN, p), wNi = h_powmod64(wLi, Lfull >> logN, p);
     const uint64_t wT = h_powmod64(wN, (1ull << logN) >> lt, p), wTi = h_powmod64(wNi, (1ull << logN) >> lt, p);
-    if (int rc = upload64(&pl->tw_fwd[lv], stage_table64(wT, lt, M))) return rc;
-    if (int rc = upload64(&pl->tw_inv[lv], stage_table64(wTi, lt, M))) return rc;
+    if (fp) {
+      if (int rc = upload64(&pl->tw_fwd[lv], fp_pairs(stage_table_plain(wT, lt, p), p))) return rc;
+      if (int rc = upload64(&pl->tw_inv[lv], fp_pairs(stage_table_plain(wTi, lt, p), p))) return rc;
+    } else {
+      if (int rc = upload64(&pl->tw_fwd[lv], stage_table64(wT, lt, M))) return rc;
+      if (int rc = upload64(&pl->tw_inv[lv], stage_table64(wTi, lt, M))) return rc;
+    }
     if (lv < pl->npass - 1) {
       const int logS = logN - lt;
-      if (int rc = upload64(&pl->fs_fwd[lv], fourstep_table64(wN, lt, logS, 1, M))) return rc;
-      if (int rc = upload64(&pl->fs_inv[lv], fourstep_table64(wNi, lt, logS, lv == 0 ? ninv : 1, M))) return rc;
+      if (fp) {
+        if (int rc = upload64(&pl->fs_fwd[lv], fp_pairs(fourstep_table_plain(wN, lt, logS, 1, p), p))) return rc;
+        if (int rc = upload64(&pl->fs_inv[lv], fp_pairs(fourstep_table_plain(wNi, lt, logS, lv == 0 ? ninv : 1, p), p))) return rc;
+      } else {
+        if (int rc = upload64(&pl->fs_fwd[lv], fourstep_table64(wN, lt, logS, 1, M))) return rc;
+        if (int rc = upload64(&pl->fs_inv[lv], fourstep_table64(wNi, lt, logS, lv == 0 ? ninv : 1, M))) return rc;
+      }
       logN = logS;
     }
   }
@@ -204,13 +264,14 @@ static int grid_for64(long long tiles, int cap) { return (int)std::max<long long
 static int env_int64(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 template <int MODE, bool SAFE, bool PLO1>
-static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
+static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st, bool fp = false) {
 #define NTTX_ROW64_CASE(K) case K: { \
     using Lyt = RowLayout64<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
     const int cap = K >= 12 ? (1 << 20) : cap_row;   /* long rows: one row per workgroup */ \
     if constexpr (MODE == 2) { \
-      if (A.psi_in) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
+      if (fp) { if constexpr (!SAFE && !PLO1) hipLaunchKernelGGL((rowmul64_kernel<K, false, false, false, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); } \
+      else if (A.psi_in) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
       else hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); } \
     else hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
     break; }
@@ -227,6 +288,7 @@ static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st) {
 }
 template <int MODE>
 static int launch_row64_m(const Plan64 *pl, int logT, const RowArgs64 &A, hipStream_t st) {
+  if (pl->fp) return launch_row64_t<MODE, false, false>(logT, A, st, true);
   if (pl->safe) return pl->plo1 ? launch_row64_t<MODE, true, true>(logT, A, st) : launch_row64_t<MODE, true, false>(logT, A, st);
   return pl->plo1 ? launch_row64_t<MODE, false, true>(logT, A, st) : launch_row64_t<MODE, false, false>(logT, A, st);
 }
@@ -242,7 +304,7 @@ static int launch_col64(const Plan64 *pl, bool inv, int logT, const ColArgs64 &A
   if (logT < kMinCol64 || logT > kMaxCol64 || A.logS < 4) return fail64(NTTX_ERANGE, "column pass shape unsupported (logT=%d logS=%d)", logT, A.logS);
   if (prof) prof->begin(prof->self, inv ? NTTX_K_COL_INV : NTTX_K_COL_FWD, st);
   const char *msg = nullptr;
-  int rc = launch_col64_kernels(inv, pl->safe, pl->plo1, logT, A, nvec, st, &msg);
+  int rc = launch_col64_kernels(inv, pl->safe, pl->plo1, pl->fp, logT, A, nvec, st, &msg);
   if (prof) prof->end(prof->self, st);
   if (rc) rc = fail64(rc, "%s (logT=%d logS=%d)", msg ? msg : "column pass failed", logT, A.logS);
   return rc;
@@ -260,12 +322,14 @@ static int cyclic_multiply64(Engine64 *e, const uint64_t *a, const uint64_t *b, 
                              int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof,
                              const uint64_t *psi_in, const uint64_t *psi_out) {
   Plan64 *pl;
-  if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
+  // plain products of moduli below 1.35e15 run on the floating-point class; inputs there must be canonical
+  const bool fp = engine64_fp_ok(p) && !psi_in;
+  if (int rc = get_plan64(e, p, logL, false, &pl, fp)) return rc;
   const long long len = 1ll << logL;
   if (psi_in && pl->npass > 2) return fail64(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
   if (pl->npass == 1) {
     RowArgs64 R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
-    R.ctx = pl->ctx; R.pre = pl->pre_single; R.canon_out = 1; R.nrows = batch;
+    R.ctx = pl->ctx; R.pre = pl->pre_single; R.pre_q = pl->pre_q; R.int_in = 1; R.canon_out = 1; R.nrows = batch;
     R.psi_in = psi_in; R.psi_out = psi_out;
     return launch_row64(pl, 2, pl->lt[0], R, st, prof);
   }
@@ -279,12 +343,13 @@ static int cyclic_multiply64(Engine64 *e, const uint64_t *a, const uint64_t *b, 
     C.nblocks = ((long long)batch << logL) >> logN;
     C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
     if (lv == 0 && psi_in) { C.psi = psi_in; C.nvalid = 0; }
+    C.int_in = (lv == 0);
     if (int rc = launch_col64(pl, false, pl->lt[lv], C, 2, st, prof)) return rc;
     logN = C.logS;
   }
   {
     RowArgs64 R{}; R.in0 = wa; R.in1 = wb; R.out = c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
-    R.ctx = pl->ctx; R.pre = pl->ctx.r2; R.canon_out = 0; R.nrows = ((long long)batch << logL) >> pl->lt[ncol];
+    R.ctx = pl->ctx; R.pre = pl->fp ? 0 : pl->ctx.r2; R.canon_out = 0; R.nrows = ((long long)batch << logL) >> pl->lt[ncol];
     if (int rc = launch_row64(pl, 2, pl->lt[ncol], R, st, prof)) return rc;
   }
   for (int lv = ncol - 1; lv >= 0; --lv) {
@@ -381,8 +446,8 @@ int engine64_forward(Engine64 *e, uint64_t *x, int logL, uint64_t p, int inverse
 
 int engine64_pad(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *pa, uint64_t *pb, int n, int logL,
                  uint64_t p, int batch, hipStream_t st) {
-  Plan64 *pl;
-  if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
+  Plan64 *pl;     // the plan the product will take: single-pass plans read the whole zero-padded row
+  if (int rc = get_plan64(e, p, logL, false, &pl, engine64_fp_ok(p))) return rc;
   PadArgs64 P{}; P.src[0] = a; P.src[1] = b; P.dst[0] = pa; P.dst[1] = pb; P.ctx = pl->ctx; P.n = n; P.len = 1 << logL;
   P.zfill = pl->npass == 1 ? P.len : n;
   if (pl->plo1) hipLaunchKernelGGL((pad64_kernel<true>), ew_grid64(P.zfill, batch, 2), dim3(256), 0, st, P);

@@ -24,7 +24,9 @@ const char *engine64_error();
 // p takes the 64-bit direct path for products of length 2^logL
 bool engine64_ok(uint64_t p, int logL);
 // passes chosen for a length (up to 3), returns the count
-int engine64_decompose(int logL, uint64_t p, int lt[3]);   // the pass sizes depend on the modulus (lazy-reduction headroom)
+int engine64_decompose(int logL, uint64_t p, int lt[3], bool fp = false);   // the pass sizes depend on the modulus and the arithmetic class
+// p runs its plain products on the floating-point class
+bool engine64_fp_ok(uint64_t p);
 
 // c = cyclic product of a and b, all [batch][2^logL] u64 device arrays, inputs below 2p, outputs
 // canonical.  nvalid > 0: only the first nvalid words of each input vector are read.

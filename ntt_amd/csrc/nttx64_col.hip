@@ -39,8 +39,30 @@ static int launch_col64_c(bool safe, bool plo1, int logT, const ColArgs64 &A, in
   return plo1 ? launch_col64_t<INV, false, true, ZHI>(logT, A, nvec, st) : launch_col64_t<INV, false, false, ZHI>(logT, A, nvec, st);
 }
 
-int launch_col64_kernels(bool inv, bool safe, bool plo1, int logT, const ColArgs64 &A, int nvec, hipStream_t st, const char **msg) {
+template <bool INV, bool ZHI>
+static int launch_col64_fp(int logT, const ColArgs64 &A, int nvec, hipStream_t st) {
+  const long long tiles = A.nblocks << (A.logS - 4);
+  static const int cap_col = env_int("NTTX_GRID_COL64", 1 << 20);
+  const int grid = grid_for(tiles, std::max(1, cap_col / nvec));
+#define NTTX_COL64FP_CASE(K) case K: \
+    hipLaunchKernelGGL((col64_kernel<K, INV, false, false, ZHI, false, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
+  switch (logT) {
+    NTTX_COL64FP_CASE(6) NTTX_COL64FP_CASE(7) NTTX_COL64FP_CASE(8) NTTX_COL64FP_CASE(9)
+    default: return colfail(NTTX_ERANGE, "column pass of this size unsupported");
+  }
+#undef NTTX_COL64FP_CASE
+  if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
+  return 0;
+}
+
+int launch_col64_kernels(bool inv, bool safe, bool plo1, bool fp, int logT, const ColArgs64 &A, int nvec, hipStream_t st, const char **msg) {
   g_msg = nullptr;
+  if (fp) {
+    const int rc = inv ? launch_col64_fp<true, false>(logT, A, nvec, st)
+                       : (A.nvalid > 0 ? launch_col64_fp<false, true>(logT, A, nvec, st) : launch_col64_fp<false, false>(logT, A, nvec, st));
+    if (msg) *msg = g_msg;
+    return rc;
+  }
   const int rc = inv ? launch_col64_c<true, false>(safe, plo1, logT, A, nvec, st)
                      : (A.nvalid > 0 ? launch_col64_c<false, true>(safe, plo1, logT, A, nvec, st)
                                      : launch_col64_c<false, false>(safe, plo1, logT, A, nvec, st));

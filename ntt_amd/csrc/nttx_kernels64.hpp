@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "nttx_arith.hpp"
 
 namespace nttx {
@@ -68,6 +69,8 @@ struct PrimeArgs64 {
 
 template <bool SAFE, bool PLO1>
 struct Arith64 {
+  using Tw = uint64_t;                 // a twiddle: w R mod p
+  static constexpr bool kFP = false;
   uint64_t p, npinv, p2;
   __device__ __forceinline__ Arith64(const PrimeArgs64 &c) : p(c.p), npinv(c.npinv), p2(2 * c.p) {}
   __device__ __forceinline__ uint64_t mul(uint64_t x, uint64_t w) const { return mont64_lazy<PLO1>(x, w, p, npinv); }
@@ -88,7 +91,8 @@ struct Arith64 {
     }
   }
   // Cooley-Tukey: (a, b) -> (a + b w, a - b w)
-  __device__ __forceinline__ void dit(uint64_t &a, uint64_t &b, uint64_t w, bool unit_w, int s) const {
+  __device__ __forceinline__ void dit(uint64_t &a, uint64_t &b, uint64_t w, bool unit_w, int s, int /*stage in unit*/ = 0,
+                                      int /*stages of the unit*/ = 0) const {
     const uint64_t t = unit_w ? b : mul(b, w);
     if constexpr (SAFE) {
       b = csub64(a - t + p2, p2);
@@ -106,11 +110,73 @@ struct Arith64 {
   }
 };
 
+// ------------------------------------------------------------------------------------
+// Floating-point class for p < 1.35e15 (2^50.26): residues travel as doubles holding integers of magnitude
+// at most 1.5 p (the bit pattern in the same 64-bit words), twiddles as pairs (w, w/p rounded).
+//   x w mod p:  h = fl(x w), l = fma(x, w, -h)  (x w = h + l exactly);  q = rndne(x * (w/p));  r = fma(-q, p, h) + l.
+// h - q p is an integer of magnitude below 2^53, so the fused multiply-add returns it exactly and r = x w - q p with
+// |q - x w / p| <= 0.5 + |x| 2^-52, i.e. |r| <= (0.5 + |x| / 2^52) p.  Every operand of a product or of a reduction
+// x - rndne(x / p) p is a sum of two stored values, at most 3.25 p < 2^52, so every result is at most 1.5 p again
+// (products of two stored values: q from h / p, |r| <= 1.63 p).  Six FP64 instructions replace the fourteen integer
+// ones of a 64-bit Montgomery product; FP64 issues at the rate of v_mad_u64_u32 on gfx950.
+// ------------------------------------------------------------------------------------
+struct TwF { double w, wq; };
+struct ArithFP {
+  using Tw = TwF;
+  static constexpr bool kFP = true;
+  double p, pinv;
+  uint64_t pi;
+  __device__ __forceinline__ ArithFP(const PrimeArgs64 &c) : p((double)c.p), pinv(1.0 / (double)c.p), pi(c.p) {}
+  __device__ __forceinline__ static double D(uint64_t x) { return __longlong_as_double((long long)x); }
+  __device__ __forceinline__ static uint64_t U(double x) { return (uint64_t)__double_as_longlong(x); }
+  __device__ __forceinline__ double fpmod(double x, const TwF &w) const {
+    const double h = x * w.w;
+    const double l = __builtin_fma(x, w.w, -h);
+    const double q = __builtin_rint(x * w.wq);
+    return __builtin_fma(-q, p, h) + l;
+  }
+  __device__ __forceinline__ double fpred(double x) const { return __builtin_fma(-__builtin_rint(x * pinv), p, x); }
+  __device__ __forceinline__ uint64_t mul(uint64_t x, const TwF &w) const { return U(fpmod(D(x), w)); }
+  // product of two stored values
+  __device__ __forceinline__ uint64_t mul2(uint64_t x, uint64_t y) const {
+    const double a = D(x), b = D(y);
+    const double h = a * b;
+    const double l = __builtin_fma(a, b, -h);
+    const double q = __builtin_rint(h * pinv);
+    return U(__builtin_fma(-q, p, h) + l);
+  }
+  __device__ __forceinline__ void dif(uint64_t &a, uint64_t &b, const TwF &w, bool unit_w, bool zhi, int) const {
+    const double x = D(a), y = D(b);
+    if (zhi) { b = unit_w ? a : U(fpmod(x, w)); return; }
+    const double d = x - y;
+    a = U(fpred(x + y));
+    b = U(unit_w ? fpred(d) : fpmod(d, w));
+  }
+  // Cooley-Tukey butterfly.  The sums a +- b w are reduced after the second stage of a unit only (and in units of one
+  // stage, and where w = 1 leaves b unreduced): with unit inputs at most 1.63 p the first stage leaves at most
+  // 1.63 + (0.5 + 1.63 rho) p <= 2.62 p (rho = p / 2^52 < 0.3), the second reduces to 0.5 p, the third leaves at most
+  // 0.5 + (0.5 + 0.5 rho) p <= 1.15 p: every operand stays below 3.25 p and every stored value below 1.5 p.
+  __device__ __forceinline__ void dit(uint64_t &a, uint64_t &b, const TwF &w, bool unit_w, int, int st = 1, int nst = 1) const {
+    const double x = D(a), t = unit_w ? D(b) : fpmod(D(b), w);
+    if (unit_w || st == 1 || nst == 1) { a = U(fpred(x + t)); b = U(fpred(x - t)); }
+    else { a = U(x + t); b = U(x - t); }
+  }
+  // canonical integer below 2^53 -> stored form
+  __device__ __forceinline__ static uint64_t from_int(uint64_t v) { return U((double)v); }
+  // stored form -> canonical integer residue
+  __device__ __forceinline__ uint64_t canon(uint64_t x, uint64_t) const {
+    double r = fpred(D(x));
+    if (r < 0.0) r += p;
+    if (r >= p) r -= p;
+    return (uint64_t)r;
+  }
+};
+
 // radix-2^R unit on registers, stages at point distances 2^(R-1) D ... D (forward) or D ... (inverse);
 // w[m] = tw[lo + m*D]; D1: D == 1, where the twiddles of local index 0 equal 1; sbase = index of
 // the unit's first stage inside its pass (for the LAZY bounds)
 template <int R, bool INV, bool D1, bool ZHI, class AR>
-__device__ __forceinline__ void unit64(uint64_t (&x)[1 << R], const uint64_t (&w)[1 << R], const AR &M, int sbase) {
+__device__ __forceinline__ void unit64(uint64_t (&x)[1 << R], const typename AR::Tw (&w)[1 << R], const AR &M, int sbase) {
   constexpr int NP = 1 << R;
   if constexpr (!INV) {
 #pragma unroll
@@ -131,7 +197,7 @@ __device__ __forceinline__ void unit64(uint64_t (&x)[1 << R], const uint64_t (&w
       for (int i = 0; i < NP; ++i) {
         if (i & half) continue;
         const int j = i & (half - 1);
-        M.dit(x[i], x[i + half], w[half + j], D1 && j == 0, sbase + st);
+        M.dit(x[i], x[i + half], w[half + j], D1 && j == 0, sbase + st, st, R);
       }
     }
   }
@@ -170,7 +236,7 @@ struct ColLayout64 {
 
 // one round: every radix-2^R unit at distance 2^LOGD of every transform of the tile, NV vectors
 template <class L, int R, int LOGD, bool INV, class AR, int NV, bool ZHI>
-__device__ __forceinline__ void ntt_round64(uint64_t *const (&s)[NV], const uint64_t *tw, const AR &M) {
+__device__ __forceinline__ void ntt_round64(uint64_t *const (&s)[NV], const typename AR::Tw *tw, const AR &M) {
   constexpr int D = 1 << LOGD;
   constexpr int LOG_UNITS = L::LOGT - R;
   constexpr int TOTAL = L::NT << LOG_UNITS;
@@ -182,8 +248,8 @@ __device__ __forceinline__ void ntt_round64(uint64_t *const (&s)[NV], const uint
     const int lo = u & (D - 1), hi = u >> LOGD;
     const int base = (hi << (LOGD + R)) + lo;
     const int a0 = L::addr(c, base);
-    uint64_t w[NP];
-    w[0] = 0;
+    typename AR::Tw w[NP];
+    w[0] = typename AR::Tw{};
 #pragma unroll
     for (int m = 1; m < NP; ++m) w[m] = tw[lo + m * D];
 #pragma unroll
@@ -199,7 +265,7 @@ __device__ __forceinline__ void ntt_round64(uint64_t *const (&s)[NV], const uint
 }
 
 template <class L, int REM, class AR, int NV, bool ZTOP>
-__device__ __forceinline__ void dif_rounds64(uint64_t *const (&s)[NV], const uint64_t *tw, const AR &M) {
+__device__ __forceinline__ void dif_rounds64(uint64_t *const (&s)[NV], const typename AR::Tw *tw, const AR &M) {
   constexpr bool zt = ZTOP && REM == L::LOGT;
   if constexpr (REM > 3) {
     ntt_round64<L, 3, REM - 3, false, AR, NV, zt>(s, tw, M);
@@ -211,7 +277,7 @@ __device__ __forceinline__ void dif_rounds64(uint64_t *const (&s)[NV], const uin
 }
 
 template <class L, int REM, class AR, int NV>
-__device__ __forceinline__ void dit_rounds64(uint64_t *const (&s)[NV], const uint64_t *tw, const AR &M) {
+__device__ __forceinline__ void dit_rounds64(uint64_t *const (&s)[NV], const typename AR::Tw *tw, const AR &M) {
   if constexpr (REM > 3) {
     dit_rounds64<L, REM - 3, AR, NV>(s, tw, M);
     __syncthreads();
@@ -237,11 +303,15 @@ struct RowArgs64 {
   // negacyclic products (TWIST kernels, rows = whole vectors): inputs times psi_in[i] on the way in, outputs times
   // psi_out[i] on the way out (Montgomery form, T words each)
   const uint64_t *psi_in, *psi_out;
+  // floating-point class: tables hold (w, w/p) pairs of doubles; pre / pre_q = n^-1 and n^-1 / p as doubles on
+  // single-pass lengths (0: none); int_in: the inputs are integers (first pass of a product), else stored doubles
+  uint64_t pre_q;
+  int int_in;
 };
 
-template <class L, bool TW = false, class AR = void>
+template <class L, bool TW = false, class AR = void, bool CVT = false>
 __device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long long row0, long long nrows,
-                                           const uint64_t *psi = nullptr, const AR *M = nullptr) {
+                                           const uint64_t *psi = nullptr, const AR *M = nullptr, bool cvt = false) {
   constexpr int T = L::T;
   if constexpr (T >= 2) {
     constexpr int NV2 = L::NT * T / 2;
@@ -254,6 +324,7 @@ __device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long
           const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(psi + j);
           x.x = M->mul(x.x, f.x); x.y = M->mul(x.y, f.y);
         }
+        if constexpr (CVT) { if (cvt) { x.x = AR::from_int(x.x); x.y = AR::from_int(x.y); } }
       }
       *reinterpret_cast<ulonglong2 *>(s + L::addr(c, j)) = x;
     }
@@ -321,7 +392,7 @@ __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR) row64_kernel(RowArgs6
 // all rounds of a forward pass but the last (which has R = RL stages at distance 1); rounds whose
 // twiddles lie within the first TWL table words read the LDS copy twl, the others the table itself
 template <class L, int REM, class AR, int TWL>
-__device__ __forceinline__ void dif_head64(uint64_t *s, const uint64_t *twg, const uint64_t *twl, const AR &M) {
+__device__ __forceinline__ void dif_head64(uint64_t *s, const typename AR::Tw *twg, const typename AR::Tw *twl, const AR &M) {
   if constexpr (REM > 3) {
     uint64_t *const v[1] = {s};
     ntt_round64<L, 3, REM - 3, false, AR, 1, false>(v, (8 << (REM - 3)) <= TWL ? twl : twg, M);
@@ -331,7 +402,7 @@ __device__ __forceinline__ void dif_head64(uint64_t *s, const uint64_t *twg, con
 }
 // all rounds of an inverse pass after the first
 template <class L, int REM, class AR, int TWL>
-__device__ __forceinline__ void dit_tail64(uint64_t *s, const uint64_t *twg, const uint64_t *twl, const AR &M) {
+__device__ __forceinline__ void dit_tail64(uint64_t *s, const typename AR::Tw *twg, const typename AR::Tw *twl, const AR &M) {
   if constexpr (REM > 3) {
     dit_tail64<L, REM - 3, AR, TWL>(s, twg, twl, M);
     __syncthreads();
@@ -341,12 +412,12 @@ __device__ __forceinline__ void dit_tail64(uint64_t *s, const uint64_t *twg, con
 }
 // the distance-1 round on registers: r[u*NP + q] = point q of the thread's u-th unit
 template <class L, int RL, bool INV, bool LOAD, bool STORE, class AR>
-__device__ __forceinline__ void edge_round64(uint64_t *s, const uint64_t *tw, const AR &M, uint64_t (&r)[8]) {
+__device__ __forceinline__ void edge_round64(uint64_t *s, const typename AR::Tw *tw, const AR &M, uint64_t (&r)[8]) {
   constexpr int NP = 1 << RL, NU = 8 / NP;
   constexpr int LOG_UNITS = L::LOGT - RL;
   static_assert((L::NT << LOG_UNITS) == NU * L::NTHR, "eight points per thread");
-  uint64_t w[NP];
-  w[0] = 0;
+  typename AR::Tw w[NP];
+  w[0] = typename AR::Tw{};
 #pragma unroll
   for (int m = 1; m < NP; ++m) w[m] = tw[m];     // distance 1: lo = 0
 #pragma unroll
@@ -365,42 +436,58 @@ __device__ __forceinline__ void edge_round64(uint64_t *s, const uint64_t *tw, co
 }
 
 // TWIST: negacyclic product of whole vectors (single pass, canonical output): psi factors on load and store.
-template <int LOGT, bool SAFE, bool PLO1, bool TWIST = false>
+// FP: the floating-point class (ArithFP) instead of Arith64<SAFE, PLO1>; tables are (w, w/p) pairs.
+template <int LOGT, bool SAFE, bool PLO1, bool TWIST = false, bool FP = false>
 __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1)) rowmul64_kernel(RowArgs64 A) {
+  static_assert(!(FP && TWIST), "the floating-point class has no twisted variant");
   using L = RowLayout64<LOGT>;
-  using AR = Arith64<SAFE, PLO1>;
+  using AR = typename std::conditional<FP, ArithFP, Arith64<SAFE, PLO1>>::type;
+  using Tw = typename AR::Tw;
   constexpr int T = L::T;
   constexpr int RL = (LOGT - 1) % 3 + 1;          // stages of the distance-1 round
-  // stage tables in LDS: whole up to 2^11 points; of longer rows only the first 512 words (the rounds
-  // at distance <= 64), the outer rounds read the tables through the caches
-  constexpr int TWL = (LOGT <= 11) ? T : 512;
-  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + 2 * TWL];
-  uint64_t *sa = lds, *twf = lds + L::WORDS, *twi = twf + TWL;
+  // stage tables in LDS: whole up to 2^11 points (2^9 for the 16-byte twiddles of the floating-point class); of
+  // longer rows only the first 512 entries (the rounds at distance <= 64), the outer rounds read the tables
+  // through the caches
+  constexpr int TWL = (LOGT <= (FP ? 9 : 11)) ? T : 512;
+  constexpr int TWW = sizeof(Tw) / 8;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + 2 * TWL * TWW];
+  uint64_t *sa = lds;
+  Tw *twf = reinterpret_cast<Tw *>(lds + L::WORDS), *twi = twf + TWL;
+  const Tw *gtwf = reinterpret_cast<const Tw *>(A.tw_fwd), *gtwi = reinterpret_cast<const Tw *>(A.tw_inv);
   const AR M(A.ctx);
-  for (int i = threadIdx.x; i < TWL; i += L::NTHR) { twf[i] = A.tw_fwd[i]; twi[i] = A.tw_inv[i]; }
+  for (int i = threadIdx.x; i < TWL; i += L::NTHR) { twf[i] = gtwf[i]; twi[i] = gtwi[i]; }
 
   for (long long row0 = (long long)blockIdx.x * L::NT; row0 < A.nrows; row0 += (long long)gridDim.x * L::NT) {
     uint64_t ra[8], rb[8];
     __syncthreads();
-    row_load64<L, TWIST, AR>(sa, A.in0, row0, A.nrows, A.psi_in, &M);
+    row_load64<L, TWIST, AR, FP>(sa, A.in0, row0, A.nrows, A.psi_in, &M, A.int_in != 0);
     __syncthreads();
-    dif_head64<L, LOGT, AR, TWL>(sa, A.tw_fwd, twf, M);
+    dif_head64<L, LOGT, AR, TWL>(sa, gtwf, twf, M);
     edge_round64<L, RL, false, true, false, AR>(sa, twf, M, ra);
     __syncthreads();
-    row_load64<L, TWIST, AR>(sa, A.in1, row0, A.nrows, A.psi_in, &M);
+    row_load64<L, TWIST, AR, FP>(sa, A.in1, row0, A.nrows, A.psi_in, &M, A.int_in != 0);
     __syncthreads();
-    dif_head64<L, LOGT, AR, TWL>(sa, A.tw_fwd, twf, M);
+    dif_head64<L, LOGT, AR, TWL>(sa, gtwf, twf, M);
     edge_round64<L, RL, false, true, false, AR>(sa, twf, M, rb);
     // pointwise: (a * pre) is below 2p whatever a held, so its product with b (< 2^12 p after up to 11 lazy
     // stages, p < 2^51) fits REDC; longer lazy rows leave b up to 2^14 p, so b is reduced first
+    if constexpr (FP) {     // a b, then n^-1 where this pass is the whole transform
+      const TwF pre{ArithFP::D(A.pre), ArithFP::D(A.pre_q)};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint64_t bk = (!SAFE && LOGT >= 12) ? M.mul(rb[k], A.ctx.one) : rb[k];
-      ra[k] = M.mul(M.mul(ra[k], A.pre), bk);
+      for (int k = 0; k < 8; ++k) {
+        const uint64_t ab = M.mul2(ra[k], rb[k]);
+        ra[k] = A.pre ? M.mul(ab, pre) : ab;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint64_t bk = (!SAFE && LOGT >= 12) ? M.mul(rb[k], A.ctx.one) : rb[k];
+        ra[k] = M.mul(M.mul(ra[k], A.pre), bk);
+      }
     }
     edge_round64<L, RL, true, false, true, AR>(sa, twi, M, ra);
     __syncthreads();
-    dit_tail64<L, LOGT, AR, TWL>(sa, A.tw_inv, twi, M);
+    dit_tail64<L, LOGT, AR, TWL>(sa, gtwi, twi, M);
     __syncthreads();
     constexpr int NV2 = L::NT * T / 2;
     for (int v = threadIdx.x; v < NV2; v += L::NTHR) {
@@ -434,16 +521,21 @@ struct ColArgs64 {
   long long nblocks;
   long long nvalid;
   const uint64_t *psi;   // TWIST kernels (outermost pass of a negacyclic product): psi^i forward, psi^-i inverse, N words
+  int int_in;            // floating-point class, forward: the inputs are integers (first pass of a product)
 };
 
 // TWIST: outermost pass of a negacyclic product: forward inputs times psi^i as they are read, inverse outputs times
 // psi^-i before the canonical store.
-template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI, bool TWIST = false>
+// FP: the floating-point class; tw and fs hold (w, w/p) pairs, int_in marks integer inputs (first forward pass).
+template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI, bool TWIST = false, bool FP = false>
 __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
   static_assert(!TWIST || !ZHI, "twisted passes read whole vectors");
+  static_assert(!(FP && TWIST), "the floating-point class has no twisted variant");
   constexpr int LOGC = 4, NTHR = 512;
   using L = ColLayout64<LOGT, LOGC, NTHR>;
-  using AR = Arith64<SAFE, PLO1>;
+  using AR = typename std::conditional<FP, ArithFP, Arith64<SAFE, PLO1>>::type;
+  using Tw = typename AR::Tw;
+  constexpr int TWW = sizeof(Tw) / 8;
   constexpr int T = L::T, COLS = L::COLS;
   constexpr int LPR = COLS / 2, LOG_LPR = LOGC - 1;     // lanes per row segment, 16 bytes each
   constexpr int PER = (T * LPR) / NTHR;
@@ -451,8 +543,10 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
   constexpr int PERL = ZHI ? (PER + 1) / 2 : PER;
   static_assert(PER >= 1 && PER * NTHR == T * LPR, "tile must be a whole number of pieces per thread");
   static_assert(!ZHI || (!INV && (PER % 2 == 0 || PER == 1)), "zero-half variant is forward only");
-  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + T];
-  uint64_t *s = lds, *tw = lds + L::WORDS;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[L::WORDS + T * TWW];
+  uint64_t *s = lds;
+  Tw *tw = reinterpret_cast<Tw *>(lds + L::WORDS);
+  const Tw *gtw = reinterpret_cast<const Tw *>(A.tw), *gfs = reinterpret_cast<const Tw *>(A.fs);
   const AR M(A.ctx);
   const uint64_t *in = A.in[blockIdx.z];
   uint64_t *out = A.out[blockIdx.z];
@@ -461,7 +555,7 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
   const long long ntiles = A.nblocks << log_tpb;
   const int j0 = threadIdx.x >> LOG_LPR, c2 = (threadIdx.x & (LPR - 1)) * 2;
 
-  for (int i = threadIdx.x; i < T; i += NTHR) tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < T; i += NTHR) tw[i] = gtw[i];
 
   auto tile_base = [&](long long t) -> long long {
     const long long blk = t >> log_tpb;
@@ -498,8 +592,15 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
       ulonglong2 x = nx[k];
       const int j = j0 + k * RSTEP;
       if (INV) {
-        const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
-        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
+        if constexpr (FP) {
+          const Tw *f = gfs + fbase + ((long long)j << logS) + c2;
+          x.x = M.mul(x.x, f[0]); x.y = M.mul(x.y, f[1]);
+        } else {
+          const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
+          x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
+        }
+      } else if constexpr (FP) {
+        if (A.int_in) { x.x = ArithFP::from_int(x.x); x.y = ArithFP::from_int(x.y); }
       } else if constexpr (TWIST) {
         const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi + fbase + ((long long)j << logS) + c2);
         x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
@@ -521,9 +622,15 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
       const int j = j0 + k * RSTEP;
       ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(s + L::addr(c2, j));
       if (!INV) {
-        const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
-        x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
-        if (A.canon_out) { x.x = csub64(x.x, M.p); x.y = csub64(x.y, M.p); }
+        if constexpr (FP) {
+          const Tw *f = gfs + fbase + ((long long)j << logS) + c2;
+          x.x = M.mul(x.x, f[0]); x.y = M.mul(x.y, f[1]);
+          if (A.canon_out) { x.x = M.canon(x.x, 0); x.y = M.canon(x.y, 0); }
+        } else {
+          const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.fs + fbase + ((long long)j << logS) + c2);
+          x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
+          if (A.canon_out) { x.x = csub64(x.x, M.p); x.y = csub64(x.y, M.p); }
+        }
       } else if constexpr (TWIST) {
         const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi + fbase + ((long long)j << logS) + c2);
         x.x = csub64(M.mul(x.x, f.x), M.p); x.y = csub64(M.mul(x.y, f.y), M.p);

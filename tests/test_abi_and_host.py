@@ -128,13 +128,15 @@ def test_plan_decomposition():
         assert len(lt) == 3 and sum(lt) == k and all(6 <= x <= 10 for x in lt[:2]) and lt[2] <= 11
     with pytest.raises(ntt_amd.NttxError):
         ntt_amd.plan_info(12)
-    # 64-bit lanes: the longest row pass depends on the headroom the modulus leaves (lazy class, p < 2^51)
-    id4, p50, p62 = 1337006139375617, 1125899437080577, 4611685941117976577
-    assert ntt_amd.plan_info_u64(1 << 12, id4) == [12] and ntt_amd.plan_info_u64(1 << 13, id4) == [6, 7]
-    assert ntt_amd.plan_info_u64(1 << 13, p50) == [13] and ntt_amd.plan_info_u64(1 << 13, p62) == [13]
+    # 64-bit lanes: moduli below 1.35e15 run their products on the floating-point class (no growth: rows up to 2^13);
+    # above that the lazy integer class needs 2^(k+1) p <= 2^64 for a row of k stages; the Harvey class has no limit
+    id4, top51, p62 = 1337006139375617, 2251756864012289, 4611685941117976577
+    assert ntt_amd.plan_info_u64(1 << 12, id4) == [12] and ntt_amd.plan_info_u64(1 << 13, id4) == [13]
+    assert ntt_amd.plan_info_u64(1 << 12, top51) == [12] and ntt_amd.plan_info_u64(1 << 13, top51) == [6, 7]
+    assert ntt_amd.plan_info_u64(1 << 13, p62) == [13]
     assert ntt_amd.plan_info_u64(1 << 18, id4) == [9, 9]
-    assert ntt_amd.plan_info_u64(1 << 21, id4) == [9, 12] and len(ntt_amd.plan_info_u64(1 << 22, id4)) == 3
-    assert ntt_amd.plan_info_u64(1 << 22, p50) == [9, 13]
+    assert ntt_amd.plan_info_u64(1 << 22, id4) == [9, 13] and len(ntt_amd.plan_info_u64(1 << 23, id4)) == 3
+    assert ntt_amd.plan_info_u64(1 << 21, top51) == [9, 12] and len(ntt_amd.plan_info_u64(1 << 22, top51)) == 3
 
 
 def test_harness_file_formats(tmp_path, oracle):

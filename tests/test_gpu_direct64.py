@@ -122,12 +122,13 @@ def _sparse_check(nttx, p, log_len, unit_terms):
         assert torch.equal(c[: 2 * n - 1], want[: 2 * n - 1])
 
 
-@pytest.mark.parametrize("name,log_len,passes", [("lazy_lo1", 20, 2), ("lazy_lo1", 21, 2), ("lazy_lo1", 22, 3), ("lazy", 22, 2),
-                                                 ("safe_lo1", 21, 2), ("safe", 22, 2), ("lazy_lo1", 23, 3), ("safe_lo1", 24, 3)])
+@pytest.mark.parametrize("name,log_len,passes", [("lazy_lo1", 20, 2), ("lazy_lo1", 21, 2), ("lazy_lo1", 22, 2), ("lazy", 22, 2),
+                                                 ("lazy_lo1_top", 21, 2), ("lazy_lo1_top", 22, 3), ("safe_lo1", 21, 2),
+                                                 ("safe", 22, 2), ("lazy_lo1", 23, 3), ("safe_lo1", 24, 3)])
 def test_long_lengths_sparse_factor(nttx, name, log_len, passes):
     """Two-pass plans around rows of 2^11 .. 2^13 points (2^20 .. 2^22) and three-pass plans beyond, every
-    reduction class.  A 51-bit modulus of the lazy class leaves room for 12 unreduced forward stages, not
-    13, so its 2^22 plan keeps three passes."""
+    arithmetic class (floating point below 1.35e15, lazy integer up to 2^51, Harvey beyond).  A 51-bit modulus of the
+    lazy integer class leaves room for 12 unreduced forward stages, not 13, so its 2^22 plan keeps three passes."""
     p = PRIMES[name]
     assert len(nttx.plan_info_u64(1 << log_len, p)) == passes
     _sparse_check(nttx, p, log_len, unit_terms=name.startswith("safe"))
