@@ -101,7 +101,7 @@ struct Twist64 {
 
 struct Engine64 {
   std::map<std::tuple<uint64_t, int, bool, bool>, std::unique_ptr<Plan64>> plans;
-  std::map<std::pair<uint64_t, int>, std::unique_ptr<Twist64>> twists;
+  std::map<std::tuple<uint64_t, int, bool>, std::unique_ptr<Twist64>> twists;
   Buf64 wa, wb;
   Buf64 ta, tb;      // twisted copies of the inputs of a negacyclic product
 };
@@ -270,7 +270,9 @@ static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st, bool fp 
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
     const int cap = K >= 12 ? (1 << 20) : cap_row;   /* long rows: one row per workgroup */ \
     if constexpr (MODE == 2) { \
-      if (fp) { if constexpr (!SAFE && !PLO1) hipLaunchKernelGGL((rowmul64_kernel<K, false, false, false, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); } \
+      if (fp) { if constexpr (!SAFE && !PLO1) { \
+        if (A.psi_in) hipLaunchKernelGGL((rowmul64_kernel<K, false, false, true, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
+        else hipLaunchKernelGGL((rowmul64_kernel<K, false, false, false, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); } } \
       else if (A.psi_in) hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1, true>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
       else hipLaunchKernelGGL((rowmul64_kernel<K, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); } \
     else hipLaunchKernelGGL((row64_kernel<K, MODE, SAFE, PLO1>), dim3(grid_for64(tiles, cap)), dim3(Lyt::NTHR), 0, st, A); \
@@ -320,10 +322,10 @@ int engine64_reserve(Engine64 *e, int logL, int batch) {
 // the first pass reads them and c by psi_out[i] as the last pass writes it
 static int cyclic_multiply64(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *c, int logL, uint64_t p,
                              int batch, long long nvalid, hipStream_t st, const ProfHook64 *prof,
-                             const uint64_t *psi_in, const uint64_t *psi_out) {
+                             const uint64_t *psi_in, const uint64_t *psi_out, bool psi_fp = false) {
   Plan64 *pl;
   // plain products of moduli below 1.35e15 run on the floating-point class; inputs there must be canonical
-  const bool fp = engine64_fp_ok(p) && !psi_in;
+  const bool fp = engine64_fp_ok(p) && (!psi_in || psi_fp);
   if (int rc = get_plan64(e, p, logL, false, &pl, fp)) return rc;
   const long long len = 1ll << logL;
   if (psi_in && pl->npass > 2) return fail64(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
@@ -372,7 +374,7 @@ static dim3 ew_grid64(long long per_vec, int batch, int z) {
 }
 
 static int get_twist64(Engine64 *e, Plan64 *pl, Twist64 **out) {
-  auto key = std::make_pair(pl->p, pl->logL);
+  auto key = std::make_tuple(pl->p, pl->logL, pl->fp);
   auto it = e->twists.find(key);
   if (it != e->twists.end()) { *out = it->second.get(); return 0; }
   const uint64_t p = pl->p;
@@ -385,9 +387,15 @@ static int get_twist64(Engine64 *e, Plan64 *pl, Twist64 **out) {
   const uint64_t psi = h_powmod64(g, (p - 1) >> (logL + 1), p), psii = h_powmod64(psi, p - 2, p);
   const size_t len = (size_t)1 << logL;
   std::vector<uint64_t> f(len), b(len);
-  const uint64_t sf = M.to(psi), sb = M.to(psii);
-  uint64_t cf = M.one, cb = M.one;
-  for (size_t i = 0; i < len; ++i) { f[i] = cf; b[i] = cb; cf = M.mul(cf, sf); cb = M.mul(cb, sb); }
+  if (pl->fp) {                       // plain residues, then (value, value / p) pairs of doubles
+    uint64_t cf = 1, cb = 1;
+    for (size_t i = 0; i < len; ++i) { f[i] = cf; b[i] = cb; cf = h_mulmod64(cf, psi, p); cb = h_mulmod64(cb, psii, p); }
+    f = fp_pairs(f, p); b = fp_pairs(b, p);
+  } else {
+    const uint64_t sf = M.to(psi), sb = M.to(psii);
+    uint64_t cf = M.one, cb = M.one;
+    for (size_t i = 0; i < len; ++i) { f[i] = cf; b[i] = cb; cf = M.mul(cf, sf); cb = M.mul(cb, sb); }
+  }
   std::unique_ptr<Twist64> tw(new Twist64);
   if (int rc = upload64(&tw->fwd, f)) return rc;
   if (int rc = upload64(&tw->inv, b)) return rc;
@@ -401,10 +409,18 @@ int engine64_negacyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t 
                                  int batch, hipStream_t st, const ProfHook64 *prof) {
   Plan64 *pl; Twist64 *tw;
   if (logL < 1) return fail64(NTTX_EINVAL, "length must be at least 2");
+  // one- and two-pass plans apply psi^i inside their first and last pass (on the floating-point class where the
+  // modulus allows it); three-pass plans use element-wise passes around the product on the integer classes
+  static const bool unfused = [] { const char *e_ = getenv("NTTX_TWIST_UNFUSED"); return e_ && atoi(e_) != 0; }();
+  if (engine64_fp_ok(p) && !unfused) {
+    if (int rc = get_plan64(e, p, logL, false, &pl, true)) return rc;
+    if (pl->npass <= 2) {
+      if (int rc = get_twist64(e, pl, &tw)) return rc;
+      return cyclic_multiply64(e, a, b, c, logL, p, batch, 0, st, prof, tw->fwd, tw->inv, true);
+    }
+  }
   if (int rc = get_plan64(e, p, logL, false, &pl)) return rc;
   if (int rc = get_twist64(e, pl, &tw)) return rc;
-  // one- and two-pass plans apply psi^i inside their first and last pass; three-pass plans use element-wise passes
-  static const bool unfused = [] { const char *e_ = getenv("NTTX_TWIST_UNFUSED"); return e_ && atoi(e_) != 0; }();
   if (pl->npass <= 2 && !unfused) return cyclic_multiply64(e, a, b, c, logL, p, batch, 0, st, prof, tw->fwd, tw->inv);
   const size_t vec = ((size_t)batch << logL) * 8;
   if (int rc = e->ta.ensure(vec)) return rc;

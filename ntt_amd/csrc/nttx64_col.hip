@@ -45,6 +45,7 @@ static int launch_col64_fp(int logT, const ColArgs64 &A, int nvec, hipStream_t s
   static const int cap_col = env_int("NTTX_GRID_COL64", 1 << 20);
   const int grid = grid_for(tiles, std::max(1, cap_col / nvec));
 #define NTTX_COL64FP_CASE(K) case K: \
+    if constexpr (!ZHI) { if (A.psi) { hipLaunchKernelGGL((col64_kernel<K, INV, false, false, false, true, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break; } } \
     hipLaunchKernelGGL((col64_kernel<K, INV, false, false, ZHI, false, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
   switch (logT) {
     NTTX_COL64FP_CASE(6) NTTX_COL64FP_CASE(7) NTTX_COL64FP_CASE(8) NTTX_COL64FP_CASE(9)

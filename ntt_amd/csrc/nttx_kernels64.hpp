@@ -125,8 +125,8 @@ struct ArithFP {
   using Tw = TwF;
   static constexpr bool kFP = true;
   double p, pinv;
-  uint64_t pi;
-  __device__ __forceinline__ ArithFP(const PrimeArgs64 &c) : p((double)c.p), pinv(1.0 / (double)c.p), pi(c.p) {}
+  uint64_t pi, npinv, r2;
+  __device__ __forceinline__ ArithFP(const PrimeArgs64 &c) : p((double)c.p), pinv(1.0 / (double)c.p), pi(c.p), npinv(c.npinv), r2(c.r2) {}
   __device__ __forceinline__ static double D(uint64_t x) { return __longlong_as_double((long long)x); }
   __device__ __forceinline__ static uint64_t U(double x) { return (uint64_t)__double_as_longlong(x); }
   __device__ __forceinline__ double fpmod(double x, const TwF &w) const {
@@ -161,8 +161,12 @@ struct ArithFP {
     if (unit_w || st == 1 || nst == 1) { a = U(fpred(x + t)); b = U(fpred(x - t)); }
     else { a = U(x + t); b = U(x - t); }
   }
-  // canonical integer below 2^53 -> stored form
-  __device__ __forceinline__ static uint64_t from_int(uint64_t v) { return U((double)v); }
+  // integer -> stored form; a word that is not below p (rare: callers pass residues) is reduced first, by two
+  // Montgomery reductions as in pad64_kernel
+  __device__ __forceinline__ uint64_t from_int(uint64_t v) const {
+    if (v >= pi) v = csub64(mont64_lazy<false>(mont64_lazy<false>(v, r2, pi, npinv), 1ull, pi, npinv), pi);
+    return U((double)v);
+  }
   // stored form -> canonical integer residue
   __device__ __forceinline__ uint64_t canon(uint64_t x, uint64_t) const {
     double r = fpred(D(x));
@@ -320,11 +324,16 @@ __device__ __forceinline__ void row_load64(uint64_t *s, const uint64_t *in, long
       ulonglong2 x = make_ulonglong2(0, 0);
       if (row0 + c < nrows) {
         x = *reinterpret_cast<const ulonglong2 *>(in + (row0 + c) * T + j);
+        if constexpr (CVT) { if (cvt) { x.x = M->from_int(x.x); x.y = M->from_int(x.y); } }
         if constexpr (TW) {
-          const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(psi + j);
-          x.x = M->mul(x.x, f.x); x.y = M->mul(x.y, f.y);
+          if constexpr (CVT) {      // floating-point class: the table holds (psi^i, psi^i / p) pairs
+            const typename AR::Tw *f = reinterpret_cast<const typename AR::Tw *>(psi) + j;
+            x.x = M->mul(x.x, f[0]); x.y = M->mul(x.y, f[1]);
+          } else {
+            const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(psi + j);
+            x.x = M->mul(x.x, f.x); x.y = M->mul(x.y, f.y);
+          }
         }
-        if constexpr (CVT) { if (cvt) { x.x = AR::from_int(x.x); x.y = AR::from_int(x.y); } }
       }
       *reinterpret_cast<ulonglong2 *>(s + L::addr(c, j)) = x;
     }
@@ -439,7 +448,6 @@ __device__ __forceinline__ void edge_round64(uint64_t *s, const typename AR::Tw 
 // FP: the floating-point class (ArithFP) instead of Arith64<SAFE, PLO1>; tables are (w, w/p) pairs.
 template <int LOGT, bool SAFE, bool PLO1, bool TWIST = false, bool FP = false>
 __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1)) rowmul64_kernel(RowArgs64 A) {
-  static_assert(!(FP && TWIST), "the floating-point class has no twisted variant");
   using L = RowLayout64<LOGT>;
   using AR = typename std::conditional<FP, ArithFP, Arith64<SAFE, PLO1>>::type;
   using Tw = typename AR::Tw;
@@ -494,7 +502,10 @@ __global__ void __launch_bounds__(RowLayout64<LOGT>::NTHR, (LOGT >= 12 ? 4 : 1))
       const int c = (v * 2) >> LOGT, j = (v * 2) & (T - 1);
       if (row0 + c < A.nrows) {
         ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(sa + L::addr(c, j));
-        if constexpr (TWIST) {     // the multiplication is also the reduction: below 2p, then canonical
+        if constexpr (TWIST && FP) {
+          const Tw *f = reinterpret_cast<const Tw *>(A.psi_out) + j;
+          x.x = M.canon(M.mul(x.x, f[0]), 0); x.y = M.canon(M.mul(x.y, f[1]), 0);
+        } else if constexpr (TWIST) {     // the multiplication is also the reduction: below 2p, then canonical
           const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi_out + j);
           x.x = csub64(M.mul(x.x, f.x), M.p); x.y = csub64(M.mul(x.y, f.y), M.p);
         } else if (A.canon_out) { x.x = M.canon(x.x, A.ctx.one); x.y = M.canon(x.y, A.ctx.one); }
@@ -530,7 +541,6 @@ struct ColArgs64 {
 template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI, bool TWIST = false, bool FP = false>
 __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
   static_assert(!TWIST || !ZHI, "twisted passes read whole vectors");
-  static_assert(!(FP && TWIST), "the floating-point class has no twisted variant");
   constexpr int LOGC = 4, NTHR = 512;
   using L = ColLayout64<LOGT, LOGC, NTHR>;
   using AR = typename std::conditional<FP, ArithFP, Arith64<SAFE, PLO1>>::type;
@@ -600,7 +610,11 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
           x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
         }
       } else if constexpr (FP) {
-        if (A.int_in) { x.x = ArithFP::from_int(x.x); x.y = ArithFP::from_int(x.y); }
+        if (A.int_in) { x.x = M.from_int(x.x); x.y = M.from_int(x.y); }
+        if constexpr (TWIST) {
+          const Tw *f = reinterpret_cast<const Tw *>(A.psi) + fbase + ((long long)j << logS) + c2;
+          x.x = M.mul(x.x, f[0]); x.y = M.mul(x.y, f[1]);
+        }
       } else if constexpr (TWIST) {
         const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi + fbase + ((long long)j << logS) + c2);
         x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
@@ -631,6 +645,9 @@ __global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
           x.x = M.mul(x.x, f.x); x.y = M.mul(x.y, f.y);
           if (A.canon_out) { x.x = csub64(x.x, M.p); x.y = csub64(x.y, M.p); }
         }
+      } else if constexpr (TWIST && FP) {
+        const Tw *f = reinterpret_cast<const Tw *>(A.psi) + fbase + ((long long)j << logS) + c2;
+        x.x = M.canon(M.mul(x.x, f[0]), 0); x.y = M.canon(M.mul(x.y, f[1]), 0);
       } else if constexpr (TWIST) {
         const ulonglong2 f = *reinterpret_cast<const ulonglong2 *>(A.psi + fbase + ((long long)j << logS) + c2);
         x.x = csub64(M.mul(x.x, f.x), M.p); x.y = csub64(M.mul(x.y, f.y), M.p);
