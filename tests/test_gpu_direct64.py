@@ -217,3 +217,33 @@ def test_negacyclic_product_u64(nttx, oracle, name, log_len, batch):
     assert torch.equal(da.cpu(), torch.from_numpy((a + np.array([[p] + [0] * (L - 1)] + [[0] * L] * (batch - 1), dtype=np.uint64)).view(np.int64)))
     with pytest.raises(nttx.NttxError):                      # 8191 * 2^20 + 1: no 2^21-th root
         nttx.dev_negacyclic_multiply_u64(da.data_ptr(), db.data_ptr(), dc.data_ptr(), 1 << 20, PRIMES["lazy_small"], 1, 0)
+
+
+FP_EDGE = {"fp_top": 1349999656960001,       # 80466345 * 2^24 + 1: the largest such prime of the floating-point class
+           "int_bottom": 1350000109944833}    # 80466372 * 2^24 + 1: the first above it (lazy integer class)
+
+
+@pytest.mark.parametrize("name", ["fp_top", "int_bottom", "id4"])
+@pytest.mark.parametrize("log_len", [10, 12, 13, 16, 18, 21])
+def test_floating_point_class_worst_case(nttx, oracle, name, log_len):
+    """Every coefficient p-1 (the largest operands every butterfly can see; (p-1)^2 = 1 mod p makes the product
+    min(k+1, 2n-1-k)), then random inputs against the CRT oracle, on the largest modulus of the floating-point class,
+    the first modulus beyond it and id 4's; product lengths covering one- and two-pass plans; linear and negacyclic."""
+    p = FP_EDGE.get(name, P_ID4)
+    n = 1 << (log_len - 1)
+    a = np.full(n, p - 1, dtype=np.uint64)
+    k = np.arange(2 * n - 1, dtype=np.uint64)
+    want = np.minimum(k + np.uint64(1), np.uint64(2 * n - 1) - k) % np.uint64(p)
+    assert np.array_equal(nttx.poly_multiply_direct64(a, a, n, p), want)
+    if log_len <= 18:
+        x, y = rand(oracle, n, 900 + log_len, p), rand(oracle, n, 901 + log_len, p)
+        assert np.array_equal(nttx.poly_multiply_direct64(x, y, n, p), oracle.poly_multiply_crt(x, y, p))
+    if log_len <= 16:                                    # negacyclic: (p-1)^2 x^(i+j) summed with the wrap-around sign
+        N = n
+        da = torch.from_numpy(np.full((1, N), p - 1, dtype=np.uint64).view(np.int64)).cuda()
+        dc = torch.empty_like(da)
+        nttx.dev_negacyclic_multiply_u64(da.data_ptr(), da.data_ptr(), dc.data_ptr(), N, p, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        i = np.arange(N, dtype=np.int64)
+        neg = ((i + 1) - (N - 1 - i)) % p                # (i+1) terms without wrap, (N-1-i) with sign -1
+        assert np.array_equal(dc.cpu().numpy().view(np.uint64)[0], neg.astype(np.uint64))
