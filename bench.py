@@ -34,8 +34,9 @@ EVENT_EVERY = 4             # steps of the timed region whose kernels are bracke
 MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per multiplication
 
 
-def cpu_baseline(n, p, reps=3):
-    """Time the reference CPU program itself on this host (its own chrono line)."""
+def cpu_baseline(n, p, reps=80, reps_extra=5):
+    """Time the reference CPU program itself on this host (its own chrono line): 4 * reps multiplications,
+    about ten seconds of CPU work; the other CPU programs (reported extras) run reps_extra times each."""
     import numpy as np
     from oracle import pyoracle as po
     O = po.Oracle()
@@ -62,7 +63,7 @@ def cpu_baseline(n, p, reps=3):
            "ms_per_mult": med, "note": "the reference's NTT stage uses at most 4 threads (one per CRT prime, main.cc:306)"}
     if po.have_ref():     # the pthread twin of the same four-prime program (main_pthread.cc: 4 NTT threads + CRT threads)
         try:
-            _, lat2, _ = po.run_ref_main(cases, which="ref_main_pthread", reps=reps)
+            _, lat2, _ = po.run_ref_main(cases, which="ref_main_pthread", reps=4 * reps_extra)
             ms2 = [x for k in (1, 2, 3, 4) for x in lat2.get(k, [])]
             if ms2:
                 out["main_pthread_ms_per_mult"] = statistics.median(ms2)
@@ -80,7 +81,7 @@ def cpu_baseline(n, p, reps=3):
                          ("monttry2.cpp get_result (8 threads per stage)",
                           lambda: po.RefMont("monttry2").poly_multiply(a32, b32, p))):
             ts = []
-            for _ in range(reps + 1):
+            for _ in range(reps_extra + 1):
                 t0 = time.perf_counter()
                 fn()
                 ts.append((time.perf_counter() - t0) * 1e3)
@@ -92,7 +93,7 @@ def cpu_baseline(n, p, reps=3):
         bu[:n] = b32
         R = po.RefCRT("main")
         ts = []
-        for _ in range(reps):
+        for _ in range(reps_extra):
             t0 = time.perf_counter()
             R.ntt_compute(au, bu, p)
             ts.append((time.perf_counter() - t0) * 1e3)
