@@ -1,42 +1,82 @@
 #!/usr/bin/env python3
-"""Headline benchmark: NTT polynomial multiplication at product length 2^18 on MI355X.
+"""Benchmarks of the NTT polynomial-multiplication path on MI355X.
 
-Workload (the single-prime configuration the headline metric is quoted on): prime 469762049, n = 2^17 coefficients
-per input (product length L = 2^18), a batch of independent multiplications resident in
-HBM.  A "step" is one pass of the hot path over the whole batch (batch multiplications).
-With N GPUs every rank runs its own batch (weak scaling, no data-path collective).
+  python bench.py --gpus N --steps K --warmup W [--workload single|crt|batch|fourstep]
 
-Prints ONE JSON line (rank 0).  `value` = poly-mults/s over all ranks.  `roofline` is for
-the dominant kernel, timed live with HIP events on the launch stream; `cpu_baseline` is the
-compiled reference program (oracle/_ref/ref_main = main.cc) timed on this host.
+Workloads (a "step" is one pass of the hot path over one batch of synthetic input):
+
+  single    (default, the headline metric) prime 469762049, n = 2^17 coefficients per input (product length
+            L = 2^18), a batch of independent products resident in HBM; every rank runs its own batch
+            (weak scaling, no data-path collective)
+  crt       51-bit modulus 1337006139375617 through the reference's four primes + CRT (main.cc:286-338),
+            n = 2^17: the primes are dealt to min(N, 4) ranks, ONE all-to-all hands every rank the four
+            residues of its slice of the indices, recombination on slices (ntt_amd.distributed.CrtSharded);
+            32 products per rank and step (weak scaling)
+  batch     4096 independent products of length 2^16 dealt to the ranks, no collective (strong scaling)
+  fourstep  ONE product of length 2^24 (--log-len up to 26): one rank runs the single-GPU three-pass plan,
+            N > 1 ranks split the T x S matrix by columns, two all-to-alls per product
+            (ntt_amd.distributed.FourStepSharded; strong scaling)
+
+Ranks: under `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is
+one rank.  Started plainly with --gpus N > 1 it spawns N child ranks itself, BEFORE any GPU call is made in this
+process, and relays rank 0's JSON line.  One process per GPU, RCCL ("nccl") between them.
+NTTX_BENCH_ONE_DEVICE=1 rehearses several ranks on ONE GPU (collectives staged through host memory over gloo,
+flagged in the output); --dry-run exercises only the launch / rendezvous / timing plumbing (no GPU needed).
+
+Prints ONE JSON line (rank 0).  `value` = whole-job throughput over all ranks with inputs resident in HBM.
+`roofline` is for the dominant kernel, timed live with HIP events on the launch stream, against the HBM bytes it
+moves; `cpu_baseline` (rank 0, N = 1) is the reference's CPU program for the workload timed on this host.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-P = 469762049
-LOG_L = 18
+P32 = 469762049
+P64 = 1337006139375617       # harness id 4's modulus (test.o:11)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
-# algorithmic HBM bytes per multiplication, per kernel (u32 words of length L moved once):
-#   col_fwd reads the n = L/2 coefficients of a and b (their zero padding is never read) and
-#           writes both transformed copies                  -> 1 + 2 = 3 L words
-#   row_mul reads both copies and writes the product rows   -> 3 L words
-#   col_inv reads and writes the product                    -> 2 L words
-KERNEL_WORDS = {"col_fwd": 3, "row_mul": 3, "col_inv": 2}
-RAMP_STEPS = 50             # untimed steps always run before the timed region (clock ramp)
-EVENT_EVERY = 4             # steps of the timed region whose kernels are bracketed by HIP events: every 4th
-MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per multiplication
+CLOCK_GHZ = 2.4              # MI355X peak engine clock
+SIMDS = 1024                 # 256 CUs x 4 SIMDs
+RAMP_STEPS = 50              # untimed steps always run before the timed region of the headline workload (clock ramp)
+EVENT_EVERY = 4              # steps of the timed region whose kernels are bracketed by HIP events: every 4th
+MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per single-prime product
+KERNEL_SOURCES = ("nttx_kernels.hpp", "nttx_arith.hpp", "nttx.hip", "nttx_col.hip", "nttx_launch.hpp")
 
 
-def cpu_baseline(n, p, reps=80, reps_extra=5):
-    """Time the reference CPU program itself on this host (its own chrono line): 4 * reps multiplications,
-    about ten seconds of CPU work; the other CPU programs (reported extras) run reps_extra times each."""
+def kernel_source_tag():
+    """Hash of the kernel sources: counter figures recorded under profiles/ are only quoted while it matches."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "ntt_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(name, kernel):
+    """profiles/<name>.json = {"kernel_source_tag": ..., "kernels": {kind: value}}; None when absent or stale."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
+    try:
+        rec = json.load(open(path))
+    except Exception:                                      # noqa: BLE001
+        return None, "absent"
+    if rec.get("kernel_source_tag") != kernel_source_tag():
+        return None, "stale (kernel sources changed since it was measured)"
+    return rec.get("kernels", {}).get(kernel), "current"
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines: the reference's own programs (oracle/_ref) timed on this host, bounded samples
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline_main_cc(n, p, reps=80, reps_extra=5, extras=True):
+    """main.cc itself (its own chrono line): 4 * reps products, about ten seconds of CPU work."""
     import numpy as np
     from oracle import pyoracle as po
     O = po.Oracle()
@@ -61,18 +101,19 @@ def cpu_baseline(n, p, reps=80, reps_extra=5):
     med = statistics.median(ms)
     out = {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "sample": what,
            "ms_per_mult": med, "note": "the reference's NTT stage uses at most 4 threads (one per CRT prime, main.cc:306)"}
-    if po.have_ref():     # the pthread twin of the same four-prime program (main_pthread.cc: 4 NTT threads + CRT threads)
-        try:
-            _, lat2, _ = po.run_ref_main(cases, which="ref_main_pthread", reps=4 * reps_extra)
-            ms2 = [x for k in (1, 2, 3, 4) for x in lat2.get(k, [])]
-            if ms2:
-                out["main_pthread_ms_per_mult"] = statistics.median(ms2)
-        except Exception:                                  # noqa: BLE001  (a reported extra, never fatal)
-            pass
-    # the reference's single-prime programs on the same workload (the CPU analogue of the GPU path):
-    # get_result_pthread (pthread_normal.cpp:361-413, 8 threads, Montgomery R = 2^30, conversions to and
-    # from Montgomery form included) and one ntt_compute_omp call (main.cc:185-209, Barrett, one thread)
-    if po.have_ref():
+    if not (extras and po.have_ref()):
+        return out
+    try:   # the pthread twin of the same four-prime program (main_pthread.cc: 4 NTT threads + CRT threads)
+        _, lat2, _ = po.run_ref_main(cases, which="ref_main_pthread", reps=4 * reps_extra)
+        ms2 = [x for k in (1, 2, 3, 4) for x in lat2.get(k, [])]
+        if ms2:
+            out["main_pthread_ms_per_mult"] = statistics.median(ms2)
+    except Exception:                                      # noqa: BLE001  (a reported extra, never fatal)
+        pass
+    if p < (1 << 30):
+        # the reference's single-prime programs on the same workload (the CPU analogue of the GPU path):
+        # get_result_pthread (pthread_normal.cpp:361-413, 8 threads, Montgomery R = 2^30, conversions to and
+        # from Montgomery form included) and one ntt_compute_omp call (main.cc:185-209, Barrett, one thread)
         single = {}
         a32 = np.asarray(cases[1][0], dtype=np.int32)
         b32 = np.asarray(cases[1][1], dtype=np.int32)
@@ -102,120 +143,331 @@ def cpu_baseline(n, p, reps=80, reps_extra=5):
     return out
 
 
-def main():
+def cpu_baseline_single_prime(n, p, budget_s=12.0):
+    """pthread_normal.cpp's get_result_pthread (the reference's single-prime program, 8 threads, conversions to and
+    from Montgomery form included) on products of n coefficients, for about budget_s seconds."""
+    import numpy as np
+    from oracle import pyoracle as po
+    O = po.Oracle()
+    a = np.asarray(O.fill_random(n, 1001, p), dtype=np.int32)
+    b = np.asarray(O.fill_random(n, 2001, p), dtype=np.int32)
+    if po.have_ref():
+        R = po.RefMont("pthread_normal")
+        fn = lambda: R.poly_multiply(a, b, p)              # noqa: E731
+        kind, cores = "reference", 8
+        what = "oracle/_ref/libref_pthread_normal.so (pthread_normal.cpp get_result_pthread, NUM_THREADS = 8)"
+    else:
+        fn = lambda: O.poly_multiply_mont(a, b, p)         # noqa: E731
+        kind, cores = "port", 1
+        what = "oracle/ntt_oracle.c restatement of monttry2.cpp's single-prime product (one thread)"
+    fn()
+    ts, t_end = [], time.perf_counter() + budget_s
+    while time.perf_counter() < t_end or len(ts) < 5:
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    med = statistics.median(ts)
+    return {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "ms_per_mult": med,
+            "sample": f"{what}: {len(ts)} products of n={n} coefficients, p={p}, one after the other, median"}
+
+
+def cpu_baseline_long(log_len, p):
+    """The reference's arrays stop at 300000 words (main.cc:228), so its programs cannot run these lengths; the
+    CPU figure is the oracle's restatement of ntt_compute_omp (main.cc:185-209) on heap vectors, one product."""
+    import numpy as np
+    from oracle import pyoracle as po
+    O = po.Oracle()
+    L = 1 << log_len
+    a = np.zeros(L, dtype=np.uint32)
+    b = np.zeros(L, dtype=np.uint32)
+    a[: L // 2] = O.fill_random(L // 2, 7, p)
+    b[: L // 2] = O.fill_random(L // 2, 8, p)
+    t0 = time.perf_counter()
+    O.ntt_compute(a, b, p)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "poly-mults/s", "cores": 1, "kind": "port", "ms_per_mult": dt * 1e3,
+            "sample": f"oracle/ntt_oracle.c restatement of ntt_compute_omp (main.cc:185-209), ONE product of length 2^{log_len}, "
+                      f"p={p} (the reference's own arrays stop at 300000 words, main.cc:228)"}
+
+
+# ------------------------------------------------------------------------------------------------
+# launching ranks
+# ------------------------------------------------------------------------------------------------
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=256, help="multiplications per GPU per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="single", choices=("single", "crt", "batch", "fourstep"))
+    ap.add_argument("--batch", type=int, default=0, help="single / crt: products per GPU per step; batch: products in all")
+    ap.add_argument("--log-len", type=int, default=0, help="batch: product length (16 or 17); fourstep: 24 .. 26")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-check", action="store_true", help="ablation builds only: skip the oracle spot-check")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-kernel HIP events in the timed region")
     ap.add_argument("--no-context", action="store_true", help="profiling runs: skip the device-copy and batch-1 measurements "
                     "after the timed region, so a kernel trace holds only the benchmark's own launches")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing plumbing only: the step is empty, "
+                    "no GPU is touched, the line carries dry_run: true and no value")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"single": 200, "crt": 20, "batch": 20, "fourstep": 20}[args.workload]
+    if args.warmup is None:
+        args.warmup = {"single": 50, "crt": 5, "batch": 5, "fourstep": 5}[args.workload]
+    return args
 
-    import numpy as np
-    import torch
-    import ntt_amd
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # NTTX_BENCH_ONE_DEVICE=1 (rehearsal on a one-GPU box): every rank uses GPU 0 and the control-plane
-    # collectives (barrier, max of the elapsed time) run over gloo, since RCCL wants one GPU per rank
-    rehearsal = os.environ.get("NTTX_BENCH_ONE_DEVICE") == "1"
-    device_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
-    if world > 1:
-        import torch.distributed as dist
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """Parent of a plain `python bench.py --gpus N` run: starts N fresh child ranks and waits for them.  Nothing here
+    touches the GPU (device_count() does not initialise it), so the children are ordinary child processes of a process
+    without a HIP context.  Rank 0 writes the JSON line to this process's stdout; the other ranks' stdout goes to stderr."""
+    one_device = os.environ.get("NTTX_BENCH_ONE_DEVICE") == "1"
+    if "--dry-run" not in sys.argv and not one_device:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(json.dumps({"error": f"--gpus {n} but this node shows {have} GPU(s)"}))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def relay():     # rank 0's JSON line goes to stdout, anything else a library printed there goes to stderr
+        for line in procs[0].stdout:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+
+    import threading
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    pump.join(timeout=10)
+    return rc
+
+
+class HostStagedComm:
+    """Rehearsal only (several ranks on ONE GPU, where RCCL cannot run): the collectives of a TorchComm over gloo,
+    with device tensors staged through host memory."""
+
+    def __init__(self, inner, device):
+        self._c, self._dev = inner, device
+        self.world, self.rank = inner.world, inner.rank
+
+    def all_to_all(self, send):
+        return self._c.all_to_all(send.cpu()).to(self._dev)
+
+    def all_gather(self, x):
+        return self._c.all_gather(x.cpu()).to(self._dev)
+
+    def barrier(self):
+        self._c.barrier()
+
+    def split(self, color_of_rank):
+        return HostStagedComm(self._c.split(color_of_rank), self._dev)
+
+
+class Rank:
+    """This process as one rank: device, process group, and the barrier-bracketed timer."""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.backend = None
+        self.rccl_ranks = None
+        self.rehearsal = os.environ.get("NTTX_BENCH_ONE_DEVICE") == "1"
+        self.dry = args.dry_run
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            # RCCL carries only the barrier and the max of the elapsed time here (the data path has no collective);
-            # if it cannot come up on this node, the same two calls run over gloo on host memory
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as exc:                       # noqa: BLE001
-                sys.stderr.write(f"rank {rank}: RCCL unavailable ({exc}); control-plane collectives over gloo\n")
-                if dist.is_initialized():
-                    dist.destroy_process_group()
+        if self.dry:
+            self.torch = __import__("torch")
+            self.dev = None
+            if self.world > 1:
+                import torch.distributed as dist
                 dist.init_process_group("gloo")
-                rehearsal = True                           # reductions on host tensors from here on
-    ntt_amd.init(device_index)
+                self.dist, self.backend = dist, "gloo"
+            return
+        import torch
+        self.torch = torch
+        index = 0 if self.rehearsal else self.local_rank
+        torch.cuda.set_device(index)
+        self.dev = torch.device("cuda", index)
+        self.device_index = index
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+                self.backend = "gloo (rehearsal: every rank on GPU 0, collectives staged through host memory)"
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+                probe = torch.ones(1, device=self.dev)
+                dist.all_reduce(probe)                      # brings RCCL up; the sum is the rank count it reaches
+                torch.cuda.synchronize()
+                self.rccl_ranks = int(probe.item())
+                self.backend = "nccl (RCCL)"
+            self.dist = dist
 
-    L, n, B = 1 << LOG_L, 1 << (LOG_L - 1), args.batch
-    # synthetic inputs, generated on the device: uniform in [0, p), upper half zero (padding)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    a = torch.zeros((B, L), dtype=torch.int32, device=dev)
-    b = torch.zeros((B, L), dtype=torch.int32, device=dev)
-    a[:, :n] = torch.randint(0, P, (B, n), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
-    b[:, :n] = torch.randint(0, P, (B, n), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    def comm(self):
+        from ntt_amd.distributed import ThreadComm, TorchComm
+        if self.world == 1:
+            return ThreadComm.run(1, lambda c: c)[0]
+        c = TorchComm()
+        return HostStagedComm(c, self.dev) if self.rehearsal else c
+
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        cpu = self.dry or self.rehearsal
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cpu" if cpu else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, steps, warmup, events=False):
+        """warmup untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides;
+        returns the MAX elapsed seconds over ranks.  events: every EVENT_EVERY-th step has its kernels bracketed by
+        HIP events on the launch stream (an event record keeps the next kernel from starting while the previous one
+        drains: 2.5 % on the whole step when every step carries them)."""
+        import ntt_amd
+        for _ in range(warmup):
+            step()
+        self.sync()
+        if events:
+            ntt_amd.profile_reset()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if events and i % EVENT_EVERY == 0:
+                ntt_amd.profile_enable(True)
+                step()
+                ntt_amd.profile_enable(False)
+            else:
+                step()
+        self.sync()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        return self.max_over_ranks(elapsed)
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def roofline_of(prof, bytes_per_step, launches_per_step, extra=None):
+    """Dominant kernel kind (largest share of the event-timed device time) against the HBM bytes it moves.
+    prof: {kind: (total ms, launches)}; bytes_per_step / launches_per_step: {kind: ...} of this rank."""
+    kern = {k: v for k, v in prof.items() if v[1] > 0}
+    if not kern:
+        return None, {}
+    dom = max(kern, key=lambda k: kern[k][0])
+    ms, launches = kern[dom]
+    avg_s = ms / launches * 1e-3
+    per_launch = bytes_per_step.get(dom, 0) / max(1, launches_per_step.get(dom, 1))
+    achieved = per_launch / avg_s / 1e9
+    traffic, traffic_state = recorded_counters("traffic", dom) if extra == "single" else (None, "not recorded for this workload")
+    roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_record": traffic_state,
+            "bytes": "HBM bytes the kernel moves per launch (its reads + writes, each word once)",
+            "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms / launches, "launches_timed": launches}
+    # whole step: every kernel's moved bytes over the sum of the kernels' event-timed durations
+    tot_b = sum(bytes_per_step.get(k, 0) for k in kern)
+    tot_s = sum(kern[k][0] / kern[k][1] * launches_per_step.get(k, 1) for k in kern) * 1e-3
+    roof["whole_step"] = {"moved_bytes_per_step": tot_b, "kernel_ms_per_step": tot_s * 1e3, "achieved": tot_b / tot_s / 1e9,
+                          "frac": tot_b / tot_s / 1e9 / HBM_PEAK_GBS}
+    if extra == "single":
+        insts, state = recorded_counters("valu", dom)
+        if insts:
+            # integer-VALU issue: a SIMD issues a wave64 instruction of this path in 2.5 (add/sub) to 4.5 (64-bit
+            # multiply-add) cycles; the figure below is cycles the kernel took per instruction it issued, per SIMD
+            cyc = SIMDS * CLOCK_GHZ * 1e9 * avg_s / insts
+            roof["valu"] = {"wave_instructions_per_launch": insts, "record": state,
+                            "simd_cycles_per_instruction_at_2.4GHz": cyc,
+                            "issue_rate_frac_of_one_per_cycle": 1.0 / cyc,
+                            "note": "SQ_INSTS_VALU of profiles/valu.json over 1024 SIMDs x 2.4 GHz x the live launch time; "
+                                    "butterfly code measured alone issues at about 4.6 cycles per instruction per SIMD "
+                                    "(64-bit multiply-adds 4.5, 32-bit multiplies 4.2, adds 2.5), so values near 4.6-5 mean "
+                                    "the kernel is bound by integer-VALU issue, not by HBM"}
+        else:
+            roof["valu"] = {"record": state}
+    return roof, {k: v[0] / v[1] for k, v in kern.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def rand_padded(torch, gen, dev, rows, n, length, p):
+    x = torch.zeros((rows, length), dtype=torch.int32, device=dev)
+    x[:, :n] = torch.randint(0, p, (rows, n), generator=gen, device=dev, dtype=torch.int64).to(torch.int32)
+    return x
+
+
+def run_single(R, args):
+    import numpy as np
+    import ntt_amd
+    torch = R.torch
+    LOG_L = 18
+    L, n, B = 1 << LOG_L, 1 << (LOG_L - 1), args.batch or 256
+    g = torch.Generator(device=R.dev)
+    g.manual_seed(1234 + R.rank)
+    a, b = rand_padded(torch, g, R.dev, B, n, L, P32), rand_padded(torch, g, R.dev, B, n, L, P32)
     c = torch.empty_like(a)
     ntt_amd.reserve(L, B, 1)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P, B, stream)
+        ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, B, stream)
 
     step()
     torch.cuda.synchronize()
-
-    # spot-check one product of the batch against the oracle before timing anything
-    if rank == 0 and not args.no_check:
+    if R.rank == 0 and not args.no_check:   # spot-check one product of the batch against the oracle before timing anything
         from oracle import pyoracle as po
-        O = po.Oracle()
-        ah = a[0].cpu().numpy().view(np.uint32)
-        bh = b[0].cpu().numpy().view(np.uint32)
-        want = O.ntt_compute(ah, bh, P)
-        got = c[0].cpu().numpy().view(np.uint32)
-        if not np.array_equal(got, want):
-            print(json.dumps({"error": "GPU result differs from the oracle"}))
-            sys.exit(1)
-
-    # warm-up directly before the timed region: the host-side check above leaves the GPU idle long
-    # enough for its clocks to drop
-    # (MI355X takes some 20-30 ms of load to reach its steady clocks), topped up to RAMP_STEPS steps
+        want = po.Oracle().ntt_compute(a[0].cpu().numpy().view(np.uint32), b[0].cpu().numpy().view(np.uint32), P32)
+        if not np.array_equal(c[0].cpu().numpy().view(np.uint32), want):
+            raise SystemExit(json.dumps({"error": "GPU result differs from the oracle"}))
+    # the host-side check leaves the GPU idle long enough for its clocks to drop; MI355X takes some 20-30 ms of load to
+    # reach its steady clocks, so the warm-up is topped up to RAMP_STEPS steps
     ramp = max(0, RAMP_STEPS - args.warmup)
-    for _ in range(args.warmup + ramp):
-        step()
-    torch.cuda.synchronize()
-    ntt_amd.profile_reset()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # per-kernel HIP events bracket every EVENT_EVERY-th step of the timed region: an event record keeps the
-    # next kernel from starting while the previous one drains (2.5 % on the whole step when every step carries them)
-    for i in range(args.steps):
-        if not args.no_events and i % EVENT_EVERY == 0:
-            ntt_amd.profile_enable(True)
-            step()
-            ntt_amd.profile_enable(False)
-        else:
-            step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ntt_amd.profile_enable(False)
-    prof = ntt_amd.profile_read()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.timed(step, args.steps, args.warmup + ramp, events=not args.no_events)
+    prof = ntt_amd.profile_read() if not args.no_events else {}
 
-    # two context figures, outside the timed region: what a plain device-to-device copy of the same
-    # buffers reaches on this GPU (read L*B words + write L*B words), and the latency of ONE resident product
     copy_gbs = lat1_us = None
-    if rank == 0 and not args.no_events and not args.no_context:
+    if R.rank == 0 and not args.no_context:
+        # two context figures, outside the timed region: what a plain device-to-device copy of the same buffers reaches
+        # on this GPU (read L*B words + write L*B words), and the latency of ONE resident product
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
             c.copy_(a)
@@ -226,74 +478,276 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 2 * 4 * L * B * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         for _ in range(50):
-            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P, 1, stream)
+            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, 1, stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(200):
-            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P, 1, stream)
+            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, 1, stream)
         torch.cuda.synchronize()
         lat1_us = (time.perf_counter() - t1) / 200 * 1e6
+    # HBM words each kernel moves per product (u32 words of length L moved once): col_fwd reads the n = L/2
+    # coefficients of a and b (their zero padding is never read) and writes both transformed copies (1 + 2 = 3 L words),
+    # row_mul reads both copies and writes the product rows (3 L), col_inv reads and writes the product (2 L)
+    words = {"col_fwd": 3, "row_mul": 3, "col_inv": 2}
+    mults = R.world * B * args.steps
+    res = {
+        "metric": "poly-mults/sec at product length 2^18 (single 32-bit prime)", "unit": "poly-mults/s", "dtype": "u32",
+        "units": mults, "elapsed": elapsed, "scaling": "weak", "clock_ramp_steps": ramp,
+        "config": {"workload": "configs[1]: single prime 469762049, product length 2^18 (n=2^17 per input), "
+                               "Montgomery LDS-fused NTT, batch resident in HBM",
+                   "p": P32, "log2_len": LOG_L, "batch_per_gpu": B, "passes": ntt_amd.plan_info(L),
+                   "parallelism": f"batch-sharded x{R.world}, no collective"},
+        "butterflies_per_unit": 3 * (L // 2) * LOG_L,
+        "bytes_per_step": {k: w * 4 * L * B for k, w in words.items()}, "launches_per_step": {k: 1 for k in words},
+        "prof": prof, "roofline_kind": "single",
+        "extra": {"us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6, "us_per_mult_batch_1": lat1_us,
+                  "pipeline_model": {"what": "a MODEL, not traffic: the survey's two-HBM-passes-per-transform byte count "
+                                             "(52 L per product) times the measured rate; the kernels move 32 L",
+                                     "model_bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "bytes_per_mult_moved": 32 * L,
+                                     "model_GBs_per_gpu": MODEL_BYTES_PER_L * L * (mults / R.world / elapsed) / 1e9,
+                                     "model_frac_of_peak": MODEL_BYTES_PER_L * L * (mults / R.world / elapsed) / 1e9 / HBM_PEAK_GBS}},
+        "device_copy_GBs": copy_gbs,
+        "cpu": (lambda: cpu_baseline_main_cc(n, P32)),
+    }
+    return res
 
-    if rank == 0:
-        mults = world * B * args.steps
-        value = mults / elapsed
-        butterflies = 3 * (L // 2) * LOG_L
-        kern = {k: v for k, v in prof.items() if v[1] > 0}
-        if not kern:
-            print(json.dumps({"us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6, "ms_per_step": elapsed / args.steps * 1e3, "events": False}))
+
+def run_batch(R, args):
+    import numpy as np
+    import ntt_amd
+    from ntt_amd.sharding import shard_range
+    torch = R.torch
+    logL = args.log_len or 16
+    L, n, total = 1 << logL, 1 << (logL - 1), args.batch or 4096
+    lo, hi = shard_range(total, R.rank, R.world)
+    nb = hi - lo
+    g = torch.Generator(device=R.dev)
+    g.manual_seed(4321 + R.rank)
+    a, b = rand_padded(torch, g, R.dev, nb, n, L, P32), rand_padded(torch, g, R.dev, nb, n, L, P32)
+    c = torch.empty_like(a)
+    ntt_amd.reserve(L, nb, 1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, nb, stream)
+
+    step()
+    torch.cuda.synchronize()
+    if R.rank == 0 and not args.no_check:
+        from oracle import pyoracle as po
+        want = po.Oracle().ntt_compute(a[nb - 1].cpu().numpy().view(np.uint32), b[nb - 1].cpu().numpy().view(np.uint32), P32)
+        if not np.array_equal(c[nb - 1].cpu().numpy().view(np.uint32), want):
+            raise SystemExit(json.dumps({"error": "GPU result differs from the oracle"}))
+    elapsed = R.timed(step, args.steps, args.warmup, events=not args.no_events)
+    prof = ntt_amd.profile_read() if not args.no_events else {}
+    words = {"col_fwd": 3, "row_mul": 3, "col_inv": 2}
+    return {
+        "metric": f"poly-mults/sec, {total} independent products of length 2^{logL}", "unit": "poly-mults/s", "dtype": "u32",
+        "units": total * args.steps, "elapsed": elapsed, "scaling": "strong",
+        "config": {"workload": f"configs[3]: {total} independent products of length 2^{logL} (n=2^{logL - 1} per input), prime 469762049, "
+                               "dealt to the ranks, no inter-GPU communication",
+                   "p": P32, "log2_len": logL, "batch_total": total, "batch_this_rank": nb, "passes": ntt_amd.plan_info(L),
+                   "parallelism": f"batch-sharded x{R.world}, no collective"},
+        "butterflies_per_unit": 3 * (L // 2) * logL,
+        "bytes_per_step": {k: w * 4 * L * nb for k, w in words.items()}, "launches_per_step": {k: 1 for k in words},
+        "prof": prof, "roofline_kind": "batch",
+        "extra": {"us_per_mult_per_gpu": elapsed / (nb * args.steps) * 1e6},
+        "cpu": (lambda: cpu_baseline_single_prime(n, P32)),
+    }
+
+
+def run_crt(R, args):
+    import numpy as np
+    import ntt_amd
+    from ntt_amd.distributed import CrtSharded, HipEngine
+    torch = R.torch
+    n, L = 1 << 17, 1 << 18
+    per_rank = args.batch or 32
+    total = per_rank * R.world
+    sh = CrtSharded(R.comm(), HipEngine())
+    lo, hi = sh.batch_range(total)
+    nb = hi - lo
+    gi = torch.Generator(device=R.dev)
+    gi.manual_seed(1000 + sh.br)                # the ranks of a batch group hold the same inputs
+    a = torch.randint(0, P64, (nb, n), generator=gi, device=R.dev, dtype=torch.int64)
+    b = torch.randint(0, P64, (nb, n), generator=gi, device=R.dev, dtype=torch.int64)
+    ntt_amd.reserve(L, nb, len(sh.own))
+    out = sh.multiply(a, b, n, P64, gather=True)
+    torch.cuda.synchronize()
+    if R.rank == 0 and not args.no_check:
+        from oracle import pyoracle as po
+        want = po.Oracle().poly_multiply_crt(a[0].cpu().numpy().view(np.uint64), b[0].cpu().numpy().view(np.uint64), P64)
+        if not np.array_equal(out[0].cpu().numpy().view(np.uint64), want):
+            raise SystemExit(json.dumps({"error": "GPU result differs from the oracle"}))
+    del out
+    elapsed = R.timed(lambda: sh.multiply(a, b, n, P64, gather=False), args.steps, args.warmup, events=not args.no_events)
+    prof = ntt_amd.profile_read() if not args.no_events else {}
+    k = len(sh.own)                               # primes this rank transforms for
+    sl = L // sh.gp                               # indices this rank recombines per product
+    bytes_per_step = {"col_fwd": 12 * L * nb * k, "row_mul": 12 * L * nb * k, "col_inv": 8 * L * nb * k,
+                      "split": (16 + 8 * k) * n * nb, "crt": (16 + 8) * sl * nb}
+    launches = {"col_fwd": k, "row_mul": k, "col_inv": k, "split": 1, "crt": 1}
+    exch = int(nb * L * 4 * k * (sh.gp - 1) / sh.gp)
+    return {
+        "metric": "poly-mults/sec at n=2^17 coefficients modulo a 51-bit prime (four 32-bit NTT primes + CRT)", "unit": "poly-mults/s",
+        "dtype": "u32 (transforms), u64 (split and recombination)",
+        "units": total * args.steps, "elapsed": elapsed, "scaling": "weak",
+        "config": {"workload": "configs[2]: modulus 1337006139375617 (harness id 4) via the four NTT primes of main.cc:245-248 + CRT, "
+                               "n=2^17 per input, primes dealt to ranks, one all-to-all of residue slices per step",
+                   "p": P64, "n": n, "batch_total": total, "batch_this_rank": nb, "primes_this_rank": k,
+                   "layout": {"prime_groups": sh.gp, "batch_groups": sh.gb},
+                   "parallelism": f"{sh.gp} prime group(s) x {sh.gb} batch group(s)"},
+        "butterflies_per_unit": 4 * 3 * (L // 2) * 18,
+        "bytes_per_step": bytes_per_step, "launches_per_step": launches, "prof": prof, "roofline_kind": "crt",
+        "extra": {"us_per_mult_whole_job": elapsed / (total * args.steps) * 1e6, "exchange_bytes_per_rank": exch},
+        "cpu": (lambda: cpu_baseline_main_cc(n, P64, extras=False)),
+    }
+
+
+def run_fourstep(R, args):
+    import numpy as np
+    import ntt_amd
+    from ntt_amd.distributed import FourStepSharded, HipEngine
+    torch = R.torch
+    logL = args.log_len or 24
+    L = 1 << logL
+    g = torch.Generator(device=R.dev)
+    g.manual_seed(77)                               # every rank draws the same whole vectors and keeps its slab
+    stream = torch.cuda.current_stream().cuda_stream
+    if R.world == 1:
+        a, b = rand_padded(torch, g, R.dev, 1, L // 2, L, P32), rand_padded(torch, g, R.dev, 1, L // 2, L, P32)
+        c = torch.empty_like(a)
+        ntt_amd.reserve(L, 1, 1)
+
+        def step():
+            ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), L // 2, P32, 1, stream)
+
+        step()
+        torch.cuda.synchronize()
+        if not args.no_check:
+            # a(1) b(1) = c(1) and a(-1) b(-1) = c(-1) modulo p: every coefficient of the product takes part
+            sg = torch.ones(L, dtype=torch.int64, device=R.dev)
+            sg[1::2] = -1
+            for s in (torch.ones_like(sg), sg):
+                ea, eb, ec = (int((x[0].to(torch.int64) * s).sum().item()) % P32 for x in (a, b, c))
+                if ea * eb % P32 != ec:
+                    raise SystemExit(json.dumps({"error": "GPU result fails the evaluation check"}))
+        plan = ntt_amd.plan_info(L)
+        # three passes: outer column pass (zero half never read: 1 + 2 = 3 L words), inner column pass on both copies
+        # (2 + 2 = 4 L), rows (3 L), inner inverse (2 L), outer inverse (2 L)
+        bytes_per_step = {"col_fwd": (3 + 4) * 4 * L, "row_mul": 3 * 4 * L, "col_inv": (2 + 2) * 4 * L}
+        launches = {"col_fwd": 2, "row_mul": 1, "col_inv": 2}
+        par, exch, cfg_extra = "one GPU, three-pass plan, no exchange", 0, {"passes": plan}
+    else:
+        fs = FourStepSharded(R.comm(), HipEngine(), logL, P32)
+        va = torch.randint(0, P32, (L // 2,), generator=g, device=R.dev, dtype=torch.int64).to(torch.int32)
+        vb = torch.randint(0, P32, (L // 2,), generator=g, device=R.dev, dtype=torch.int64).to(torch.int32)
+        half = fs.T // 2
+        xa = torch.zeros((fs.T, fs.cols), dtype=torch.int32, device=R.dev)
+        xb = torch.zeros_like(xa)
+        xa[:half] = va.view(half, fs.S)[:, fs.col0: fs.col0 + fs.cols]
+        xb[:half] = vb.view(half, fs.S)[:, fs.col0: fs.col0 + fs.cols]
+        wa, wb = xa.clone(), xb.clone()
+
+        def step():
+            wa.copy_(xa)
+            wb.copy_(xb)
+            return fs.multiply(wa, wb, zero_hi=True)
+
+        xc = step()
+        torch.cuda.synchronize()
+        if not args.no_check:
+            # evaluation at x = 1: partial sums of every rank's slab, combined over the ranks
+            t = torch.tensor([int(xa.to(torch.int64).sum().item()) % P32, int(xb.to(torch.int64).sum().item()) % P32,
+                              int(xc.to(torch.int64).sum().item()) % P32], dtype=torch.int64)
+            tt = t.clone() if R.rehearsal else t.to(R.dev)
+            R.dist.all_reduce(tt)
+            ea, eb, ec = (int(v) % P32 for v in tt.cpu().tolist())
+            if ea * eb % P32 != ec:
+                raise SystemExit(json.dumps({"error": "GPU result fails the evaluation check"}))
+        rows_len = fs.S
+        rplan = ntt_amd.plan_info(rows_len)
+        slab = fs.T * fs.cols                       # words of one slab = L / G
+        if len(rplan) == 1:
+            bytes_per_step = {"col_fwd": 2 * 6 * slab, "row_mul": 12 * slab, "col_inv": 8 * slab}
+            launches = {"col_fwd": 2, "row_mul": 1, "col_inv": 1}
+        else:
+            bytes_per_step = {"col_fwd": (2 * 6 + 16) * slab, "row_mul": 12 * slab, "col_inv": (8 + 8) * slab}
+            launches = {"col_fwd": 3, "row_mul": 1, "col_inv": 2}
+        par = f"columns split over {R.world} ranks, two all-to-alls per product"
+        exch = int(3 * slab * 4 * (R.world - 1) / R.world)
+        cfg_extra = {"log2_t": fs.log_t, "row_passes": rplan}
+    elapsed = R.timed(step, args.steps, args.warmup, events=not args.no_events)
+    prof = ntt_amd.profile_read() if not args.no_events else {}
+    return {
+        "metric": f"poly-mults/sec, one product of length 2^{logL} (single 32-bit prime)", "unit": "poly-mults/s", "dtype": "u32",
+        "units": args.steps, "elapsed": elapsed, "scaling": "strong",
+        "config": dict({"workload": f"configs[4]: ONE product of length 2^{logL} (n=2^{logL - 1} per input), prime 469762049, four-step NTT",
+                        "p": P32, "log2_len": logL, "parallelism": par}, **cfg_extra),
+        "butterflies_per_unit": 3 * (L // 2) * logL,
+        "bytes_per_step": bytes_per_step, "launches_per_step": launches, "prof": prof, "roofline_kind": "fourstep",
+        "extra": {"ms_per_product": elapsed / args.steps * 1e3, "exchange_bytes_per_rank": exch},
+        "cpu": (lambda: cpu_baseline_long(logL, P32)),
+    }
+
+
+def run_dry(R, args):
+    elapsed = R.timed(lambda: None, args.steps, args.warmup)
+    return {"metric": "none (dry run of the launch and timing plumbing)", "unit": "steps/s", "dtype": "none", "units": 0,
+            "elapsed": elapsed, "scaling": "weak", "config": {"workload": f"dry run of --workload {args.workload}"},
+            "butterflies_per_unit": 0, "bytes_per_step": {}, "launches_per_step": {}, "prof": {}, "roofline_kind": None,
+            "extra": {"dry_run": True}, "cpu": None}
+
+
+def run_rank(args):
+    R = Rank(args)
+    import ntt_amd
+    if not R.dry:
+        ntt_amd.init(R.device_index)
+    try:
+        fn = run_dry if R.dry else {"single": run_single, "crt": run_crt, "batch": run_batch, "fourstep": run_fourstep}[args.workload]
+        res = fn(R, args)
+        if R.rank == 0:
+            units, elapsed = res["units"], res["elapsed"]
+            value = units / elapsed if units else None
+            out = {"metric": res["metric"], "value": value, "unit": res["unit"], "n_gpus": R.world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                   "scaling": res["scaling"], "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
+                   "config": res["config"], "workload": args.workload, "backend": R.backend, "rccl_ranks": R.rccl_ranks}
+            if "clock_ramp_steps" in res:
+                out["clock_ramp_steps"] = res["clock_ramp_steps"]
+            if R.rehearsal and R.world > 1:
+                out["rehearsal"] = "NTTX_BENCH_ONE_DEVICE=1: every rank ran on GPU 0; not a multi-GPU measurement"
+            if units and res["butterflies_per_unit"]:
+                out["ns_per_butterfly"] = elapsed / (units * res["butterflies_per_unit"]) * 1e9
+            out.update(res["extra"])
+            roof, per_kernel = roofline_of(res["prof"], res["bytes_per_step"], res["launches_per_step"], res["roofline_kind"])
+            if roof is not None:
+                if res.get("device_copy_GBs"):
+                    roof["device_copy_GBs"] = res["device_copy_GBs"]
+                    roof["frac_of_device_copy"] = roof["achieved"] / res["device_copy_GBs"]
+                out["roofline"] = roof
+                out["kernels_ms_per_launch"] = per_kernel
+            elif not R.dry:
+                out["roofline"] = None
+            if R.world == 1 and not args.no_cpu and res["cpu"] is not None:
+                out["cpu_baseline"] = res["cpu"]()
+                if value:
+                    out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            print(json.dumps(out), flush=True)
+    finally:
+        R.finish()
+        if not R.dry:
             ntt_amd.shutdown()
-            return
-        dom = max(kern, key=lambda k: kern[k][0])
-        dom_ms, dom_launches = kern[dom]
-        dom_avg_s = dom_ms / dom_launches * 1e-3
-        dom_bytes = KERNEL_WORDS.get(dom, 0) * 4 * L * B
-        achieved = dom_bytes / dom_avg_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(dom)
-            except Exception:
-                traffic = None
-        model_gbs = MODEL_BYTES_PER_L * L * (value / world) / 1e9
-        out = {
-            "metric": "poly-mults/sec at product length 2^18 (single 32-bit prime)",
-            "value": value,
-            "unit": "poly-mults/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "clock_ramp_steps": ramp,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: single prime 469762049, product length 2^18 (n=2^17 per input), "
-                                   "Montgomery LDS-fused NTT, batch resident in HBM",
-                       "p": P, "log2_len": LOG_L, "batch_per_gpu": B, "passes": ntt_amd.plan_info(L),
-                       "parallelism": f"batch-sharded x{world}, no collective"},
-            "ns_per_butterfly": elapsed / (mults / world) / butterflies * 1e9,
-            "us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6,
-            "us_per_mult_batch_1": lat1_us,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms / dom_launches,
-                         "launches_timed": dom_launches,
-                         "device_copy_GBs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs if copy_gbs else None},
-            "kernels_ms_per_step": {k: v[0] / v[1] for k, v in kern.items()},
-            "pipeline_model": {"bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "achieved_GBs_per_gpu": model_gbs,
-                               "frac_of_peak": model_gbs / HBM_PEAK_GBS,
-                               "bytes_per_mult_moved": 32 * L},
-        }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(n, P)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    ntt_amd.shutdown()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -12,6 +12,12 @@
  * failure.  Calls are synchronous unless a stream argument says otherwise.  Host
  * buffers are caller-owned; nothing is retained after a call returns.  All calls
  * of one process are serialised on an internal mutex.
+ *
+ * Streams: every call of the process shares one device workspace.  A call enqueued on a
+ * different stream than the previous call's (host-buffer calls count as the null stream)
+ * first waits on the device for the work the previous stream holds, so calls on several
+ * streams are safe but do not overlap each other.  A stream handed to the library must
+ * stay alive until a later call has been made on another stream, or until nttx_shutdown.
  */
 #ifndef NTTX_H
 #define NTTX_H
@@ -32,12 +38,16 @@ extern "C" {
 /* Which arithmetic path a (p, n) pair takes. */
 #define NTTX_PATH_DIRECT32 0 /* one NTT modulo p itself: p < 2^31 prime, 2^k | p-1 (monttry2.cpp get_result) */
 #define NTTX_PATH_CRT4 1     /* the four 32-bit NTT primes + CRT of main.cc:245-338 (as few of them as keep
-                              * n*(p-1)^2 below their product: same coefficients) */
+                              * n*(p-1)^2 below their product: same coefficients; coefficients at or above p
+                              * are first reduced modulo p, so the bound holds for any input word) */
 #define NTTX_PATH_DIRECT64 2 /* one NTT modulo p itself on 64-bit lanes: 2^31 <= p < 2^62 prime, 2^k | p-1 */
 
 /* Select the GPU of this process and build the context (one process per GPU).
  * No counterpart in the reference (CPU-only program start-up, main.cc:230-270 builds
- * the Barrett/CRT constants once per process; so does this). */
+ * the Barrett/CRT constants once per process; so does this).  It takes ONE device index,
+ * not a device list: work is split over GPUs by running one process per GPU (each calls
+ * nttx_init with its own device and exchanges data through the building blocks below),
+ * never by one process driving several devices. */
 int nttx_init(int device);
 void nttx_shutdown(void);
 const char *nttx_last_error(void);

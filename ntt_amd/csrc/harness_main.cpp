@@ -8,7 +8,16 @@
 //   NTT_OUT_DIR    directory for <id>.out dumps       (default "files", main.cc:100)
 //   argv[1..2]     first and last test id             (default 0 4, main.cc:240)
 //   NTT_DEVICE     GPU ordinal                        (default 0)
+//
+// Two flavours from this one source, as the reference has two harness shapes:
+//   nttx_harness      (T, P) = (uint64_t, uint64_t): main.cc:78-128, 272-346 (every modulus, id 4 included)
+//   nttx_harness_int  (T, P) = (int, int), built with -DNTTX_HARNESS_INT: the course harness of
+//                     monttry2.cpp:134-196, 344-400 and pthread_normal.cpp:417-468, whose declared entry point is
+//                     void poly_multiply(int *a, int *b, int *ab, int n, int p); it prints the latency with the
+//                     reference's "(us)" label (monttry2.cpp:396: the figure is milliseconds there too) and, like
+//                     the reference, cannot represent id 4's 51-bit modulus (reported as an error here, garbage there)
 #include <chrono>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +26,16 @@
 #include <vector>
 
 #include "../../include/nttx.h"
+
+#ifdef NTTX_HARNESS_INT
+typedef int coef_t;
+typedef int mod_t;
+#define NTTX_LATENCY_UNIT "(us)"
+#else
+typedef uint64_t coef_t;
+typedef uint64_t mod_t;
+#define NTTX_LATENCY_UNIT "(ms)"
+#endif
 
 static std::string data_dir() { const char *d = getenv("NTT_DATA_DIR"); return d ? d : "/nttdata"; }
 static std::string out_dir() { const char *d = getenv("NTT_OUT_DIR"); return d ? d : "files"; }
@@ -45,22 +64,29 @@ static bool next_u64(const char *&s, uint64_t &v) {
 }
 
 // n p a[0..n) b[0..n)   (fRead, main.cc:78-95)
-static bool fRead(std::vector<uint64_t> &a, std::vector<uint64_t> &b, int *n, uint64_t *p, int id) {
+static bool fRead(std::vector<coef_t> &a, std::vector<coef_t> &b, int *n, mod_t *p, int id) {
   std::vector<char> buf;
   if (!slurp(data_dir() + "/" + std::to_string(id) + ".in", buf)) return false;
   const char *s = buf.data();
-  uint64_t nn;
-  if (!next_u64(s, nn) || !next_u64(s, *p)) return false;
+  uint64_t nn, pp, x;
+  if (!next_u64(s, nn) || !next_u64(s, pp)) return false;
+#ifdef NTTX_HARNESS_INT
+  if (pp > (uint64_t)INT_MAX) {
+    fprintf(stderr, "%d.in: modulus %llu does not fit the (int, int) harness flavour\n", id, (unsigned long long)pp);
+    return false;
+  }
+#endif
   *n = (int)nn;
+  *p = (mod_t)pp;
   a.resize(nn);
   b.resize(nn);
-  for (uint64_t i = 0; i < nn; ++i) if (!next_u64(s, a[i])) return false;
-  for (uint64_t i = 0; i < nn; ++i) if (!next_u64(s, b[i])) return false;
+  for (uint64_t i = 0; i < nn; ++i) { if (!next_u64(s, x)) return false; a[i] = (coef_t)x; }
+  for (uint64_t i = 0; i < nn; ++i) { if (!next_u64(s, x)) return false; b[i] = (coef_t)x; }
   return true;
 }
 
 // 2n-1 lines (fWrite, main.cc:97-109)
-static void fWrite(const std::vector<uint64_t> &ab, int n, int id) {
+static void fWrite(const std::vector<coef_t> &ab, int n, int id) {
   FILE *f = fopen((out_dir() + "/" + std::to_string(id) + ".out").c_str(), "w");
   if (!f) return;
   std::string text;
@@ -75,25 +101,35 @@ static void fWrite(const std::vector<uint64_t> &ab, int n, int id) {
 }
 
 // compare with <id>.out (fCheck, main.cc:111-128); also returns the verdict
-static bool fCheck(const std::vector<uint64_t> &ab, int n, int id) {
+static bool fCheck(const std::vector<coef_t> &ab, int n, int id) {
   std::vector<char> buf;
   bool ok = slurp(data_dir() + "/" + std::to_string(id) + ".out", buf);
   const char *s = ok ? buf.data() : "";
   for (int i = 0; ok && i < 2 * n - 1; ++i) {
     uint64_t x;
-    if (!next_u64(s, x) || x != ab[i]) ok = false;
+    if (!next_u64(s, x) || x != (uint64_t)ab[i]) ok = false;
   }
   puts(ok ? "多项式乘法结果正确" : "多项式乘法结果错误");
   return ok;
 }
 
-// the harness-declared entry point (monttry2.cpp:344), 64-bit flavour of main.cc
-static void poly_multiply(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
+#ifdef NTTX_HARNESS_INT
+// the harness-declared entry point exactly as monttry2.cpp:344 / pthread_normal.cpp:352 declare it
+void poly_multiply(int *a, int *b, int *ab, int n, int p) {
+  if (nttx_poly_multiply_i32(a, b, ab, n, p) != 0) {
+    fprintf(stderr, "poly_multiply failed: %s\n", nttx_last_error());
+    exit(2);
+  }
+}
+#else
+// the same entry point in the 64-bit flavour of main.cc (its timed block main.cc:283-341)
+void poly_multiply(uint64_t *a, uint64_t *b, uint64_t *ab, int n, uint64_t p) {
   if (nttx_poly_multiply_u64(a, b, ab, n, p) != 0) {
     fprintf(stderr, "poly_multiply failed: %s\n", nttx_last_error());
     exit(2);
   }
 }
+#endif
 
 int main(int argc, char **argv) {
   int test_begin = argc > 1 ? atoi(argv[1]) : 0, test_end = argc > 2 ? atoi(argv[2]) : 4;
@@ -105,21 +141,21 @@ int main(int argc, char **argv) {
   printf("nttx: MI355X HIP engine, device %d\n", dv ? atoi(dv) : 0);
   bool all_ok = true;
   for (int id = test_begin; id <= test_end; ++id) {
-    std::vector<uint64_t> a, b;
+    std::vector<coef_t> a, b;
     int n_ = 0;
-    uint64_t p_ = 0;
+    mod_t p_ = 0;
     if (!fRead(a, b, &n_, &p_, id)) {
       fprintf(stderr, "cannot read %s/%d.in\n", data_dir().c_str(), id);
       all_ok = false;
       continue;
     }
-    std::vector<uint64_t> ab((size_t)2 * n_);
+    std::vector<coef_t> ab((size_t)2 * n_);
     auto t0 = std::chrono::high_resolution_clock::now();
     poly_multiply(a.data(), b.data(), ab.data(), n_, p_);
     auto t1 = std::chrono::high_resolution_clock::now();
     double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     all_ok &= fCheck(ab, n_, id);
-    printf("average latency for n = %d p = %llu : %g (ms)\n", n_, (unsigned long long)p_, ms);
+    printf("average latency for n = %d p = %llu : %g " NTTX_LATENCY_UNIT "\n", n_, (unsigned long long)p_, ms);
     fWrite(ab, n_, id);
   }
   nttx_shutdown();

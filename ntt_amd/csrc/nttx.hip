@@ -73,6 +73,8 @@ struct Plan {
     for (auto q : tw_inv) if (q) (void)hipFree(q);
     for (auto q : fs_fwd) if (q) (void)hipFree(q);
     for (auto q : fs_inv) if (q) (void)hipFree(q);
+    if (fsa_fwd) (void)hipFree(fsa_fwd);
+    if (fsa_inv) (void)hipFree(fsa_inv);
   }
 };
 
@@ -177,9 +179,23 @@ struct Context {
   DevBuf outb;              // compacted output staged for the copy back
   DevBuf tmp;               // transform API scratch
   Engine64 *e64 = nullptr;  // plans and workspace of the 64-bit-lane direct path
+  // stream of the last call that touched the workspace, and the event that orders the next stream behind it
+  hipStream_t last_stream = nullptr; bool have_last = false; hipEvent_t ws_event = nullptr;
 };
 static Context *g_ctx = nullptr;
 static std::mutex g_init_mu;
+
+// Every call of the context shares one workspace (transformed copies, residue buffers, staging, the 64-bit engine's
+// buffers), and the mutex only serialises the host side.  A call enqueued on another stream than the previous one
+// therefore first waits, on the device, for everything the previous call's stream holds.
+static int enter_stream(Context *cx, hipStream_t st) {
+  if (cx->have_last && st != cx->last_stream) {
+    HIPCHK(hipEventRecord(cx->ws_event, cx->last_stream));
+    HIPCHK(hipStreamWaitEvent(st, cx->ws_event, 0));
+  }
+  cx->last_stream = st; cx->have_last = true;
+  return 0;
+}
 
 // smallest quadratic non-residue, preferring the reference's root 3 (main.cc:241)
 static uint32_t find_nonresidue(uint32_t p) {
@@ -382,8 +398,10 @@ static void set_vec(CrtArgs &A) {
   for (int k = 0; k < A.nmod; ++k) ok = ok && aligned16(A.res[k]);
   A.vec = ok ? 1 : 0;
 }
+// grid of the element-wise kernels: x covers one vector, y the batch (the kernels stride over it, so batches beyond
+// the 65535 a grid dimension may hold are legal)
 static dim3 ew_grid2(long long per_vec, int batch, int z = 1) {
-  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
+  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)std::min(batch, 65535), (unsigned)z);
 }
 static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 * 16); }
 
@@ -497,10 +515,11 @@ static int fill_crt_args(CrtArgs &A, uint64_t p) { const int all[4] = {0, 1, 2, 
 // n*(amax)*(bmax) with amax,bmax <= p-1, must stay below the product of the moduli used
 // (cf. "sum % M" main.cc:330).  The moduli are kCrtPrimes[first..first+count-1].
 static bool crt_bound_ok(uint64_t p, int n, int first = 0, int count = 4) {
-  long double lim = 1;
-  for (int k = first; k < first + count; ++k) lim *= (long double)kCrtPrimes[k];
-  const long double need = (long double)n * (long double)(p - 1) * (long double)(p - 1);
-  return need < lim * 0.999L;
+  unsigned __int128 lim = 1;                                  // at most 2^119.6
+  for (int k = first; k < first + count; ++k) lim *= kCrtPrimes[k];
+  if (p - 1 >= (1ull << 60)) return false;                    // (p-1)^2 >= 2^120 > lim
+  const unsigned __int128 sq = (unsigned __int128)(p - 1) * (p - 1);
+  return sq <= (lim - 1) / (unsigned)n;                       // n * sq < lim, exactly
 }
 // the fewest primes that keep the product exact: the smallest ones where they suffice (their transforms are the
 // cheapest: more lazy-reduction headroom, signed lanes), else the largest ones
@@ -543,6 +562,7 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
   {
     SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
     S.zfill = pl[0]->npass == 1 ? (int)len : n;   // multi-pass products never read the padding
+    S.batch = batch; S.pmod = p;
     for (int k = 0; k < ns; ++k) {
       S.dst[0][k] = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
       S.dst[1][k] = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
@@ -563,7 +583,7 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
     if (int rc = dev_cyclic_multiply(cx, pl[k], a, b, c, batch, st, n)) return rc;
     A.res[k] = c;
   }
-  A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len;
+  A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len; A.batch = batch;
   cx->prof.begin(PK_CRT, st);
   set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(A.nout, batch), dim3(256), 0, st, A);
@@ -590,6 +610,7 @@ static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_
   for (int i = 0; i < ns; ++i) if (int rc = get_plan(cx, kCrtPrimes[sel[i]], logL, false, &pl[i])) return rc;
   SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
   S.zfill = pl[0]->npass == 1 ? (int)len : n;
+  S.batch = batch; S.pmod = 0;   // no caller modulus here: words are taken as they are (main.cc:300-301)
   for (int i = 0; i < ns; ++i) {
     S.dst[0][i] = cx->pa.as<uint32_t>() + (size_t)i * batch * len;
     S.dst[1][i] = cx->pb.as<uint32_t>() + (size_t)i * batch * len;
@@ -611,7 +632,7 @@ static int dev_crt_recombine(Context *cx, const uint32_t *const r[4], uint64_t *
   CrtArgs A{};
   if (int rc = fill_crt_args(A, p)) return rc;
   for (int k = 0; k < 4; ++k) A.res[k] = r[k];
-  A.out = d_out; A.nout = (int)count; A.len = (int)count;
+  A.out = d_out; A.nout = (int)count; A.len = (int)count; A.batch = 1;
   cx->prof.begin(PK_CRT, st);
   set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(count, 1), dim3(256), 0, st, A);
@@ -712,13 +733,13 @@ static int dev_negacyclic_multiply(Context *cx, const uint32_t *a, const uint32_
   if (int rc = cx->pa.ensure(vec)) return rc;
   if (int rc = cx->pb.ensure(vec)) return rc;
   TwistArgs T{}; T.src[0] = a; T.src[1] = b; T.dst[0] = cx->pa.as<uint32_t>(); T.dst[1] = cx->pb.as<uint32_t>();
-  T.tab = tw->fwd; T.ctx = pl->ctx; T.len = (int)len;
+  T.tab = tw->fwd; T.ctx = pl->ctx; T.len = (int)len; T.batch = batch;
   cx->prof.begin(PK_MISC, st);
   hipLaunchKernelGGL(twist_kernel, ew_grid2(len, batch, 2), dim3(256), 0, st, T);
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), c, batch, st)) return rc;
-  TwistArgs U{}; U.src[0] = c; U.dst[0] = c; U.tab = tw->inv; U.ctx = pl->ctx; U.len = (int)len;
+  TwistArgs U{}; U.src[0] = c; U.dst[0] = c; U.tab = tw->inv; U.ctx = pl->ctx; U.len = (int)len; U.batch = batch;
   cx->prof.begin(PK_MISC, st);
   hipLaunchKernelGGL(twist_kernel, ew_grid2(len, batch, 1), dim3(256), 0, st, U);
   cx->prof.end(st);
@@ -746,6 +767,10 @@ using namespace nttx;
   if (!g_ctx) return fail(NTTX_ENOINIT, "nttx_init has not been called"); \
   Context *cx = g_ctx; \
   HIPCHK(hipSetDevice(cx->device));
+// entry points that use the shared workspace on stream st (host-buffer calls: the null stream)
+#define NTTX_ENTER_ON(st) \
+  NTTX_ENTER(); \
+  if (int rc_ = enter_stream(cx, (hipStream_t)(st))) return rc_;
 
 extern "C" {
 
@@ -763,6 +788,7 @@ int nttx_init(int device) {
   g_ctx = new Context;
   g_ctx->device = device;
   g_ctx->e64 = engine64_create();
+  HIPCHK(hipEventCreateWithFlags(&g_ctx->ws_event, hipEventDisableTiming));
   (void)crt_const();
   return 0;
 }
@@ -777,6 +803,7 @@ void nttx_shutdown(void) {
   g_ctx->twists.clear();
   engine64_destroy(g_ctx->e64);
   g_ctx->prof.destroy();
+  if (g_ctx->ws_event) (void)hipEventDestroy(g_ctx->ws_event);
   for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
     b->release();
   delete g_ctx;
@@ -844,7 +871,7 @@ int nttx_reserve(int len, int batch, int nprimes) {
 }
 
 int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_c || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
   int k = 0; while ((1ll << k) < len) ++k;
   Plan *pl;
@@ -853,14 +880,14 @@ int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, in
 }
 
 int nttx_dev_negacyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_c || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
   int k = 0; while ((1ll << k) < len) ++k;
   return dev_negacyclic_multiply(cx, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, k, p, batch, (hipStream_t)stream);
 }
 
 int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_c || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
   Plan *pl;
   if (int rc = get_plan(cx, p, log2_ceil_len(n), false, &pl)) return rc;
@@ -868,13 +895,13 @@ int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int 
 }
 
 int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_ab || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
   return dev_crt_multiply(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint64_t *)d_ab, n, p, batch, (hipStream_t)stream);
 }
 
 int nttx_dev_crt_residues_u64(const void *d_a, const void *d_b, void *d_res, int n, int prime_mask, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_res || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
   return dev_crt_residues(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint32_t *)d_res, n, prime_mask, batch, (hipStream_t)stream);
 }
@@ -927,13 +954,13 @@ static int dev_ntt_impl(Context *cx, uint32_t *d_x, int len, uint32_t p, int inv
 }
 
 int nttx_dev_ntt_u32(void *d_x, int len, uint32_t p, int inverse, int bit_reversed_out, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_x || batch < 1 || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
   return dev_ntt_impl(cx, (uint32_t *)d_x, len, p, inverse, bit_reversed_out, batch, (hipStream_t)stream);
 }
 
 int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   if (!x || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two");
   if (int rc = cx->in_a.ensure((size_t)len * 4)) return rc;
   HIPCHK(hipMemcpy(cx->in_a.ptr, x, (size_t)len * 4, hipMemcpyHostToDevice));
@@ -943,7 +970,7 @@ int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse) {
 }
 
 int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, int len, uint32_t p) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   if (!a || !b || !c || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
   int k = 0; while ((1ll << k) < len) ++k;
   Plan *pl;
@@ -960,7 +987,7 @@ int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, 
 }
 
 int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, int nout, uint64_t p) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   if (!res || !ab || len < 1 || nout < 1 || nout > len) return fail(NTTX_EINVAL, "bad arguments");
   const size_t bytes = (size_t)len * 4;
   if (int rc = cx->pc.ensure(4 * bytes)) return rc;
@@ -973,7 +1000,7 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
     HIPCHK(hipMemcpy(d, res[k], bytes, hipMemcpyHostToDevice));
     A.res[k] = d;
   }
-  A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len;
+  A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len; A.batch = 1;
   set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(nout, 1), dim3(256), 0, 0, A);
   HIPCHK(hipGetLastError());
@@ -1000,20 +1027,20 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   {
     PadArgs P{}; P.src[0] = cx->in_a.as<uint32_t>(); P.src[1] = cx->in_b.as<uint32_t>();
     P.dst[0] = cx->pa.as<uint32_t>(); P.dst[1] = cx->pb.as<uint32_t>(); P.ctx = pl->ctx; P.n = n; P.len = (int)len;
-    P.zfill = pl->npass == 1 ? (int)len : n;
+    P.zfill = pl->npass == 1 ? (int)len : n; P.batch = batch;
     hipLaunchKernelGGL(pad_kernel, ew_grid2(P.zfill, batch, 2), dim3(256), 0, 0, P);
     HIPCHK(hipGetLastError());
   }
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), batch, nullptr, n)) return rc;
   const long long tout = (long long)batch * nout;
-  hipLaunchKernelGGL((unpad_kernel<uint32_t>), ew_grid2(nout, batch), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len);
+  hipLaunchKernelGGL((unpad_kernel<uint32_t>), ew_grid2(nout, batch), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len, batch);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)tout * 4, hipMemcpyDeviceToHost));
   return 0;
 }
 
 int nttx_poly_multiply_batch_u32(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   if (!a || !b || !ab || n < 1 || batch < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
   if (!direct_ok(p, log2_ceil_len(n))) return fail(NTTX_EINVAL, "modulus %u has no direct transform of this length; use the u64 entry point", p);
   return host_direct_u32(cx, a, b, ab, n, p, batch);
@@ -1022,7 +1049,7 @@ int nttx_poly_multiply_batch_u32(const uint32_t *a, const uint32_t *b, uint32_t 
 int nttx_poly_multiply_i32(const int32_t *a, const int32_t *b, int32_t *ab, int n, int32_t p) {
   if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
   if (nttx_path_for((uint64_t)p, n) == NTTX_PATH_DIRECT32) {
-    NTTX_ENTER();
+    NTTX_ENTER_ON(nullptr);
     return host_direct_u32(cx, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)ab, n, (uint32_t)p, 1);
   }
   std::vector<uint64_t> wa(n), wb(n), wc(2 * (size_t)n - 1);
@@ -1033,7 +1060,7 @@ int nttx_poly_multiply_i32(const int32_t *a, const int32_t *b, int32_t *ab, int 
 }
 
 int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
   const size_t raw = (size_t)n * 8, nout = 2 * (size_t)n - 1;
   if (int rc = cx->in_a.ensure(raw)) return rc;
@@ -1048,7 +1075,7 @@ int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *a
 
 int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
   if (!a || !b || !ab || n < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   const int logL = log2_ceil_len(n);
   if (!engine64_ok(p, logL)) return fail(NTTX_EINVAL, "modulus %llu has no direct 64-bit transform of length 2^%d", (unsigned long long)p, logL);
   const long long len = 1ll << logL;
@@ -1073,7 +1100,7 @@ int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t
 }
 
 int nttx_dev_negacyclic_multiply_u64(const void *d_a, const void *d_b, void *d_c, int len, uint64_t p, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_c || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments (len must be a power of two >= 2)");
   int k = 0; while ((1 << k) < len) ++k;
   const ProfHook64 ph = prof_hook(cx);
@@ -1082,7 +1109,7 @@ int nttx_dev_negacyclic_multiply_u64(const void *d_a, const void *d_b, void *d_c
 }
 
 int nttx_dev_direct_multiply_u64(const void *d_a, const void *d_b, void *d_c, int n, uint64_t p, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_c || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
   const ProfHook64 ph = prof_hook(cx);
   return fail_from64(engine64_cyclic_multiply(cx->e64, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint64_t *)d_c,
@@ -1090,7 +1117,7 @@ int nttx_dev_direct_multiply_u64(const void *d_a, const void *d_b, void *d_c, in
 }
 
 int nttx_dev_ntt_u64(void *d_x, int len, uint64_t p, int inverse, int batch, void *stream) {
-  NTTX_ENTER();
+  NTTX_ENTER_ON(stream);
   if (!d_x || batch < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
   int k = 0; while ((1ll << k) < len) ++k;
   const ProfHook64 ph = prof_hook(cx);
@@ -1109,7 +1136,7 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   const int path = nttx_path_for(p, n);
   if (path == NTTX_PATH_DIRECT64) return nttx_poly_multiply_direct_u64(a, b, ab, n, p);
   if (path != NTTX_PATH_DIRECT32) return nttx_poly_multiply_crt_u64(a, b, ab, n, p);
-  NTTX_ENTER();
+  NTTX_ENTER_ON(nullptr);
   // direct path on 32-bit lanes: reduce the u64 coefficients mod p on the device (one modulus)
   const int logL = log2_ceil_len(n);
   Plan *pl;
@@ -1127,14 +1154,14 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
   {
     SplitArgs S{}; S.src[0] = cx->in_a.as<uint64_t>(); S.src[1] = cx->in_b.as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len;
-    S.zfill = pl->npass == 1 ? (int)len : n;
+    S.zfill = pl->npass == 1 ? (int)len : n; S.batch = 1; S.pmod = 0;
     S.dst[0][0] = cx->pa.as<uint32_t>(); S.dst[1][0] = cx->pb.as<uint32_t>(); S.ctx[0] = pl->ctx;
     set_vec(S);
     hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, 1, 2), dim3(256), 0, 0, S);
   }
   HIPCHK(hipGetLastError());
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr, n)) return rc;
-  hipLaunchKernelGGL((unpad_kernel<uint64_t>), ew_grid2(nout, 1), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len);
+  hipLaunchKernelGGL((unpad_kernel<uint64_t>), ew_grid2(nout, 1), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
   return 0;

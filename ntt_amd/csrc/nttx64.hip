@@ -370,7 +370,7 @@ int engine64_cyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t *b, 
 }
 
 static dim3 ew_grid64(long long per_vec, int batch, int z) {
-  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)batch, (unsigned)z);
+  return dim3((unsigned)std::max<long long>(1, std::min<long long>((per_vec + 255) / 256, 1024)), (unsigned)std::min(batch, 65535), (unsigned)z);
 }
 
 static int get_twist64(Engine64 *e, Plan64 *pl, Twist64 **out) {
@@ -426,14 +426,14 @@ int engine64_negacyclic_multiply(Engine64 *e, const uint64_t *a, const uint64_t 
   if (int rc = e->ta.ensure(vec)) return rc;
   if (int rc = e->tb.ensure(vec)) return rc;
   uint64_t *ta = (uint64_t *)e->ta.ptr, *tb = (uint64_t *)e->tb.ptr;
-  Twist64Args T{}; T.src[0] = a; T.src[1] = b; T.dst[0] = ta; T.dst[1] = tb; T.tab = tw->fwd; T.ctx = pl->ctx; T.len = 1 << logL; T.canon = 0;
+  Twist64Args T{}; T.src[0] = a; T.src[1] = b; T.dst[0] = ta; T.dst[1] = tb; T.tab = tw->fwd; T.ctx = pl->ctx; T.len = 1 << logL; T.canon = 0; T.batch = batch;
   if (prof) prof->begin(prof->self, NTTX_K_MISC, st);
   if (pl->plo1) hipLaunchKernelGGL((twist64_kernel<true>), ew_grid64(T.len / 2, batch, 2), dim3(256), 0, st, T);
   else hipLaunchKernelGGL((twist64_kernel<false>), ew_grid64(T.len / 2, batch, 2), dim3(256), 0, st, T);
   if (prof) prof->end(prof->self, st);
   HIPCHK64(hipGetLastError());
   if (int rc = engine64_cyclic_multiply(e, ta, tb, c, logL, p, batch, 0, st, prof)) return rc;
-  Twist64Args U{}; U.src[0] = c; U.dst[0] = c; U.tab = tw->inv; U.ctx = pl->ctx; U.len = 1 << logL; U.canon = 1;
+  Twist64Args U{}; U.src[0] = c; U.dst[0] = c; U.tab = tw->inv; U.ctx = pl->ctx; U.len = 1 << logL; U.canon = 1; U.batch = batch;
   if (prof) prof->begin(prof->self, NTTX_K_MISC, st);
   if (pl->plo1) hipLaunchKernelGGL((twist64_kernel<true>), ew_grid64(U.len / 2, batch, 1), dim3(256), 0, st, U);
   else hipLaunchKernelGGL((twist64_kernel<false>), ew_grid64(U.len / 2, batch, 1), dim3(256), 0, st, U);
@@ -465,7 +465,7 @@ int engine64_pad(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *pa
   Plan64 *pl;     // the plan the product will take: single-pass plans read the whole zero-padded row
   if (int rc = get_plan64(e, p, logL, false, &pl, engine64_fp_ok(p))) return rc;
   PadArgs64 P{}; P.src[0] = a; P.src[1] = b; P.dst[0] = pa; P.dst[1] = pb; P.ctx = pl->ctx; P.n = n; P.len = 1 << logL;
-  P.zfill = pl->npass == 1 ? P.len : n;
+  P.zfill = pl->npass == 1 ? P.len : n; P.batch = batch;
   if (pl->plo1) hipLaunchKernelGGL((pad64_kernel<true>), ew_grid64(P.zfill, batch, 2), dim3(256), 0, st, P);
   else hipLaunchKernelGGL((pad64_kernel<false>), ew_grid64(P.zfill, batch, 2), dim3(256), 0, st, P);
   HIPCHK64(hipGetLastError());
@@ -473,7 +473,7 @@ int engine64_pad(Engine64 *e, const uint64_t *a, const uint64_t *b, uint64_t *pa
 }
 
 int engine64_unpad(const uint64_t *src, uint64_t *dst, int nout, int logL, int batch, hipStream_t st) {
-  hipLaunchKernelGGL(unpad64_kernel, ew_grid64(nout, batch, 1), dim3(256), 0, st, src, dst, nout, 1 << logL);
+  hipLaunchKernelGGL(unpad64_kernel, ew_grid64(nout, batch, 1), dim3(256), 0, st, src, dst, nout, 1 << logL, batch);
   HIPCHK64(hipGetLastError());
   return 0;
 }

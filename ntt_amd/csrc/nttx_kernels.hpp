@@ -1090,14 +1090,23 @@ struct SplitArgs {
   int nmod;
   int n, len, zfill;
   int vec;                  // n % 4 == 0 and all pointers 16-byte aligned
+  int batch;                // vectors per input; gridDim.y strides over them
+  uint64_t pmod;            // != 0: coefficients at or above pmod are first reduced modulo it (the caller's modulus)
 };
 __device__ __forceinline__ uint32_t split_one(uint64_t x, const PrimeCtx &c) {
   const uint32_t h = csub(mont_mul_lazy((uint32_t)(x >> 32), c.r2, c.p, c.npinv), c.p);   // hi * 2^32 mod m
   const uint32_t l = csub(mont_mul_lazy((uint32_t)x, c.one, c.p, c.npinv), c.p);          // lo mod m
   return csub(h + l, c.p);
 }
+// Coefficients are canonical in the reference's harness (fRead main.cc:78-95 reads residues), but main.cc:300-301
+// accepts any 64-bit word; one at or above the caller's modulus is reduced modulo it first, so that the
+// exactness bound n*(p-1)^2 of the CRT path holds for every input (a rare, divergent branch).
+__device__ __forceinline__ uint64_t split_in(uint64_t x, uint64_t pmod) {
+  if (pmod != 0 && x >= pmod) x %= pmod;
+  return x;
+}
 static __global__ void split_kernel(SplitArgs A) {
-  const long long b = blockIdx.y;
+ for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
   const uint64_t *src = A.src[blockIdx.z] + b * A.n;
   if (A.vec) {   // rows are 16-byte aligned: four coefficients per thread, 16-byte accesses
     for (int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4; j < A.zfill; j += gridDim.x * blockDim.x * 4) {
@@ -1105,6 +1114,8 @@ static __global__ void split_kernel(SplitArgs A) {
       if (j < A.n) {
         x01 = *reinterpret_cast<const ulonglong2 *>(src + j);
         x23 = *reinterpret_cast<const ulonglong2 *>(src + j + 2);
+        x01.x = split_in(x01.x, A.pmod); x01.y = split_in(x01.y, A.pmod);
+        x23.x = split_in(x23.x, A.pmod); x23.y = split_in(x23.y, A.pmod);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1115,15 +1126,16 @@ static __global__ void split_kernel(SplitArgs A) {
         }
       }
     }
-    return;
+    continue;
   }
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
-    const uint64_t x = (j < A.n) ? src[j] : 0ull;
+    const uint64_t x = (j < A.n) ? split_in(src[j], A.pmod) : 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < A.nmod) A.dst[blockIdx.z][k][b * A.len + j] = split_one(x, A.ctx[k]);
     }
   }
+ }
 }
 
 // i32 / u32 coefficients -> zero-padded canonical residues; src [batch][n] -> dst [batch][len]
@@ -1132,15 +1144,17 @@ struct PadArgs {
   uint32_t *dst[2];
   PrimeCtx ctx;
   int n, len, zfill;
+  int batch;
 };
 static __global__ void pad_kernel(PadArgs A) {
-  const long long b = blockIdx.y;
-  const uint32_t *src = A.src[blockIdx.z] + b * A.n;
-  uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
-    const uint32_t x = (j < A.n) ? src[j] : 0u;
-    // inputs are canonical in the reference's harness; anything larger is reduced like main.cc:300 does
-    dst[j] = x >= A.ctx.p ? csub(mont_mul_lazy(x, A.ctx.one, A.ctx.p, A.ctx.npinv), A.ctx.p) : x;
+  for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
+    const uint32_t *src = A.src[blockIdx.z] + b * A.n;
+    uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
+      const uint32_t x = (j < A.n) ? src[j] : 0u;
+      // inputs are canonical in the reference's harness; anything larger is reduced like main.cc:300 does
+      dst[j] = x >= A.ctx.p ? csub(mont_mul_lazy(x, A.ctx.one, A.ctx.p, A.ctx.npinv), A.ctx.p) : x;
+    }
   }
 }
 
@@ -1152,21 +1166,23 @@ struct TwistArgs {
   const uint32_t *tab;
   PrimeCtx ctx;
   int len;
+  int batch;
 };
 static __global__ void twist_kernel(TwistArgs A) {
-  const long long b = blockIdx.y;
-  const uint32_t *src = A.src[blockIdx.z] + b * A.len;
-  uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.len; i += gridDim.x * blockDim.x)
-    dst[i] = mont_mul(src[i], A.tab[i], A.ctx.p, A.ctx.npinv);
+  for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
+    const uint32_t *src = A.src[blockIdx.z] + b * A.len;
+    uint32_t *dst = A.dst[blockIdx.z] + b * A.len;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.len; i += gridDim.x * blockDim.x)
+      dst[i] = mont_mul(src[i], A.tab[i], A.ctx.p, A.ctx.npinv);
+  }
 }
 
 // gather the first nout words of every length-len vector (u32 -> u32 or u64)
 template <class OUT>
-__global__ void unpad_kernel(const uint32_t *src, OUT *dst, int nout, int len) {
-  const long long b = blockIdx.y;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
-    dst[b * nout + j] = (OUT)src[b * len + j];
+__global__ void unpad_kernel(const uint32_t *src, OUT *dst, int nout, int len, int batch) {
+  for (long long b = blockIdx.y; b < batch; b += gridDim.y)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
+      dst[b * nout + j] = (OUT)src[b * len + j];
 }
 
 // Multi-prime CRT recombination (replaces the 128-bit sum/% M loop of main.cc:323-337):
@@ -1186,6 +1202,7 @@ struct CrtArgs {
   int e;                    // p = 2^e * q
   int nmod, nout, len;
   int vec;                  // len % 4 == 0 and every residue pointer 16-byte aligned: 16-byte loads
+  int batch;                // vectors; gridDim.y strides over them
 };
 // x = v0 + m0 v1 + m0 m1 v2 + m0 m1 m2 v3 with 31-bit digits: S = sum v_k cR[k] < 2^33 q is reduced by
 // ONE 128-bit REDC (S / 2^64 < q / 2^31, so the result is at most q and one subtraction finishes).
@@ -1227,7 +1244,7 @@ __device__ __forceinline__ uint64_t crt_one(const CrtArgs &A, const uint32_t (&r
 }
 // four consecutive indices per thread (16-byte residue loads) when the rows allow it
 static __global__ void crt_kernel(CrtArgs A) {
-  const long long b = blockIdx.y;
+ for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
   uint64_t *out = A.out + b * A.nout;
   if (A.vec) {
     for (int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4; j < A.nout; j += gridDim.x * blockDim.x * 4) {
@@ -1241,7 +1258,7 @@ static __global__ void crt_kernel(CrtArgs A) {
       if (j + 2 < A.nout) out[j + 2] = crt_one(A, r2);
       if (j + 3 < A.nout) out[j + 3] = crt_one(A, r3);
     }
-    return;
+    continue;
   }
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.nout; j += gridDim.x * blockDim.x) {
     uint32_t r[4];
@@ -1249,6 +1266,7 @@ static __global__ void crt_kernel(CrtArgs A) {
     for (int k = 0; k < 4; ++k) r[k] = (k < A.nmod) ? A.res[k][b * A.len + j] : 0u;
     out[j] = crt_one(A, r);
   }
+ }
 }
 
 }  // namespace nttx

@@ -665,19 +665,21 @@ struct PadArgs64 {
   uint64_t *dst[2];
   PrimeArgs64 ctx;
   int n, len, zfill;
+  int batch;
 };
 template <bool PLO1>
 __global__ void pad64_kernel(PadArgs64 A) {
-  const long long b = blockIdx.y;
-  const uint64_t *src = A.src[blockIdx.z] + b * A.n;
-  uint64_t *dst = A.dst[blockIdx.z] + b * A.len;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
-    uint64_t x = (j < A.n) ? src[j] : 0ull;
-    if (x >= A.ctx.p) {   // x -> x R -> x, each step a REDC that leaves a value below 2p
-      const uint64_t xr = mont64_lazy<PLO1>(x, A.ctx.r2, A.ctx.p, A.ctx.npinv);
-      x = csub64(mont64_lazy<PLO1>(xr, 1ull, A.ctx.p, A.ctx.npinv), A.ctx.p);
+  for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
+    const uint64_t *src = A.src[blockIdx.z] + b * A.n;
+    uint64_t *dst = A.dst[blockIdx.z] + b * A.len;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
+      uint64_t x = (j < A.n) ? src[j] : 0ull;
+      if (x >= A.ctx.p) {   // x -> x R -> x, each step a REDC that leaves a value below 2p
+        const uint64_t xr = mont64_lazy<PLO1>(x, A.ctx.r2, A.ctx.p, A.ctx.npinv);
+        x = csub64(mont64_lazy<PLO1>(xr, 1ull, A.ctx.p, A.ctx.npinv), A.ctx.p);
+      }
+      dst[j] = x;
     }
-    dst[j] = x;
   }
 }
 
@@ -689,26 +691,28 @@ struct Twist64Args {
   const uint64_t *tab;
   PrimeArgs64 ctx;
   int len, canon;
+  int batch;
 };
 template <bool PLO1>
 __global__ void twist64_kernel(Twist64Args A) {
-  const long long b = blockIdx.y;
-  const uint64_t *src = A.src[blockIdx.z] + b * A.len;
-  uint64_t *dst = A.dst[blockIdx.z] + b * A.len;
-  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2; i < A.len; i += gridDim.x * blockDim.x * 2) {
-    const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(src + i), f = *reinterpret_cast<const ulonglong2 *>(A.tab + i);
-    ulonglong2 y;
-    y.x = mont64_lazy<PLO1>(x.x, f.x, A.ctx.p, A.ctx.npinv);
-    y.y = mont64_lazy<PLO1>(x.y, f.y, A.ctx.p, A.ctx.npinv);
-    if (A.canon) { y.x = csub64(y.x, A.ctx.p); y.y = csub64(y.y, A.ctx.p); }
-    *reinterpret_cast<ulonglong2 *>(dst + i) = y;
+  for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
+    const uint64_t *src = A.src[blockIdx.z] + b * A.len;
+    uint64_t *dst = A.dst[blockIdx.z] + b * A.len;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2; i < A.len; i += gridDim.x * blockDim.x * 2) {
+      const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(src + i), f = *reinterpret_cast<const ulonglong2 *>(A.tab + i);
+      ulonglong2 y;
+      y.x = mont64_lazy<PLO1>(x.x, f.x, A.ctx.p, A.ctx.npinv);
+      y.y = mont64_lazy<PLO1>(x.y, f.y, A.ctx.p, A.ctx.npinv);
+      if (A.canon) { y.x = csub64(y.x, A.ctx.p); y.y = csub64(y.y, A.ctx.p); }
+      *reinterpret_cast<ulonglong2 *>(dst + i) = y;
+    }
   }
 }
 
-static __global__ void unpad64_kernel(const uint64_t *src, uint64_t *dst, int nout, int len) {
-  const long long b = blockIdx.y;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
-    dst[b * nout + j] = src[b * len + j];
+static __global__ void unpad64_kernel(const uint64_t *src, uint64_t *dst, int nout, int len, int batch) {
+  for (long long b = blockIdx.y; b < batch; b += gridDim.y)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x)
+      dst[b * nout + j] = src[b * len + j];
 }
 
 }  // namespace nttx

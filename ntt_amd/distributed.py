@@ -263,6 +263,10 @@ class CrtSharded:
         else this rank's slice [nb][len/Gp] of the coefficient indices (slice q = indices
         q*len/Gp .. (q+1)*len/Gp - 1, of which only those below 2n-1 are meaningful)."""
         gp = self.gp
+        # all four moduli are in play here whatever p is; the product is exact only while n*(p-1)^2 stays below their
+        # product ("sum % M", main.cc:330) - the same check, and the same NTTX_ERANGE, as the single-GPU entry point
+        from . import api
+        api.crt_primes_for(p, n)
         res = self.engine.crt_residues(a, b, n, self.mask)              # [nown][nb][len]
         nown, nb, length = res.shape
         if gp == 1:

@@ -100,14 +100,22 @@ def test_crt_prime_selection():
     assert ntt_amd.crt_primes_for((1 << 36) - 5, n) == primes[1:]          # needs the three largest
     assert ntt_amd.crt_primes_for(65537, n) == primes[:2]
     assert ntt_amd.crt_primes_for(97, 4) == primes[:1]
-    for ns in (1, 2, 3):
+    # the bound is exact: the largest p with n*(p-1)^2 < product is p = isqrt((product-1)//n) + 1
+    from math import isqrt
+    for ns in (1, 2, 3, 4):
         for subset in (primes[:ns], primes[4 - ns:]):
             prod = 1
             for m in subset:
                 prod *= m
-            edge = int((prod * 0.999 / n) ** 0.5)
-            assert len(ntt_amd.crt_primes_for(edge - edge // 100000 - 3, n)) <= ns
-            assert len(ntt_amd.crt_primes_for(edge + edge // 100000 + 3, n)) >= (ns if subset == primes[:ns] else ns + 1)
+            top = isqrt((prod - 1) // n) + 1
+            assert n * (top - 1) ** 2 < prod <= n * top ** 2
+            assert len(ntt_amd.crt_primes_for(top, n)) <= ns
+            if ns == 4:
+                with pytest.raises(ntt_amd.NttxError) as e:
+                    ntt_amd.crt_primes_for(top + 1, n)
+                assert e.value.code == -2
+            else:
+                assert len(ntt_amd.crt_primes_for(top + 1, n)) >= (ns if subset == primes[:ns] else ns + 1)
     with pytest.raises(ntt_amd.NttxError):
         ntt_amd.crt_primes_for((1 << 61) - 1, n)
 

@@ -3,6 +3,7 @@ seeded inputs.  Integer work: the bar is bit-exact equality."""
 import hashlib
 import json
 import os
+from math import isqrt
 
 import numpy as np
 import pytest
@@ -96,8 +97,8 @@ def test_crt_fewer_primes_bound(nttx, oracle):
                 prod = 1
                 for m in subset:
                     prod *= m
-                edge = int((prod * 0.999 / n) ** 0.5)
-                moduli += [edge - edge // 100000 - 3, edge + edge // 100000 + 3]
+                top = isqrt((prod - 1) // n) + 1          # the largest modulus with n*(p-1)^2 below the product
+                moduli += [top, top + 1]
         for p in moduli:
             if nttx.path_for(p, n) != nttx.PATH_CRT4:
                 p += 1                      # an NTT-friendly prime would take a direct route: step off it
@@ -246,6 +247,115 @@ def test_inputs_not_reduced(nttx, oracle):
     assert np.array_equal(nttx.poly_multiply(a, b, n, p, dtype=np.uint64), want)
 
 
+def test_crt_route_inputs_above_modulus(nttx, oracle):
+    """The CRT route with coefficients far above p (legal for the uint64_t flavour, main.cc:300-301 reduces per
+    prime): the route picks fewer than four primes from n*(p-1)^2, so words at or above p must be reduced modulo p
+    first.  Host and device-resident entry points against the reference's four-prime product, which is exact
+    here (n * 2^45 * 2^45 stays below its M)."""
+    import torch
+    n, batch = 100, 3
+    for p in (1000000007, 65539, 97, 281474976710597, 12345678, 3 << 20):
+        assert nttx.path_for(p, n) == nttx.PATH_CRT4       # none of these has the roots a direct route needs
+        a = np.stack([rand(oracle, n, 40 + i, 1 << 45) for i in range(batch)])
+        b = np.stack([rand(oracle, n, 50 + i, 1 << 45) for i in range(batch)])
+        a[0, 0], b[0, 0], a[1, 5] = p, p - 1, (1 << 45) - 1
+        want = np.stack([oracle.poly_multiply_crt(a[i], b[i], p) for i in range(batch)])
+        assert np.array_equal(want[0], oracle.poly_multiply_naive_u64(a[0] % p, b[0] % p, p))
+        for i in range(batch):
+            assert np.array_equal(nttx.poly_multiply_crt(a[i], b[i], n, p), want[i]), (p, i)
+            assert np.array_equal(nttx.poly_multiply(a[i], b[i], n, p, dtype=np.uint64), want[i]), (p, i)
+        da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        dc = torch.empty((batch, 2 * n - 1), dtype=torch.int64, device="cuda")
+        nttx.dev_crt_multiply_u64(da.data_ptr(), db.data_ptr(), dc.data_ptr(), n, p, batch, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy().view(np.uint64), want), p
+
+
+def test_crt_exact_bound_edge(nttx, oracle):
+    """n*(p-1)^2 < M decides exactly: the largest admissible modulus multiplies worst-case inputs correctly with all
+    four primes, the next one is refused."""
+    big_m = 469762049 * 998244353 * 1004535809 * 1224736769
+    for n in (1000, 4096):
+        top = isqrt((big_m - 1) // n) + 1
+        while nttx.path_for(top, n) != nttx.PATH_CRT4:
+            top -= 1
+        assert n * (top - 1) ** 2 < big_m
+        worst = np.full(n, top - 1, dtype=np.uint64)
+        assert np.array_equal(nttx.poly_multiply_crt(worst, worst, n, top), oracle.poly_multiply_crt(worst, worst, top)), (n, top)
+        over = isqrt((big_m - 1) // n) + 2
+        with pytest.raises(nttx.NttxError) as e:
+            nttx.poly_multiply_crt(worst, worst, n, over)
+        assert e.value.code == -2
+
+
+def test_batch_beyond_grid_dimension(nttx, oracle):
+    """70000 products in one call: the element-wise kernels (pad, unpad, split, CRT) stride over the batch instead of
+    putting it into a grid dimension, which holds at most 65535."""
+    import torch
+    batch, n = 70000, 32
+    p = 469762049
+    a = rand(oracle, n * batch, 5, p).reshape(batch, n).astype(np.uint32)
+    b = rand(oracle, n * batch, 6, p).reshape(batch, n).astype(np.uint32)
+    got = nttx.poly_multiply_batch(a, b, p)
+    probe = [0, 1, 65534, 65535, 65536, 65537, batch - 1]
+    for i in probe:
+        assert np.array_equal(got[i].astype(np.uint64), oracle.poly_multiply_crt(a[i].astype(np.uint64), b[i].astype(np.uint64), p)), i
+    # every product: c(1) = a(1) b(1) and c(-1) = a(-1) b(-1) modulo p
+    sign = np.where(np.arange(2 * n - 1) % 2 == 0, 1, -1).astype(np.int64)
+    a64, b64, c64 = a.astype(np.int64), b.astype(np.int64), got.astype(np.int64)
+    for sg in (np.ones(2 * n - 1, np.int64), sign):
+        ea, eb, ec = (a64 * sg[:n]).sum(1) % p, (b64 * sg[:n]).sum(1) % p, (c64 * sg).sum(1) % p
+        assert np.array_equal(ec, np.array([int(x) * int(y) % p for x, y in zip(ea, eb)], dtype=np.int64))
+    # the CRT route on device arrays at the same batch
+    q = 1000000007
+    a8, b8 = (a.astype(np.uint64) % q), (b.astype(np.uint64) % q)
+    da, db = torch.from_numpy(a8.view(np.int64)).cuda(), torch.from_numpy(b8.view(np.int64)).cuda()
+    dc = torch.empty((batch, 2 * n - 1), dtype=torch.int64, device="cuda")
+    nttx.dev_crt_multiply_u64(da.data_ptr(), db.data_ptr(), dc.data_ptr(), n, q, batch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got8 = dc.cpu().numpy().view(np.uint64)
+    for i in probe:
+        assert np.array_equal(got8[i], oracle.poly_multiply_crt(a8[i], b8[i], q)), i
+    c8 = got8.astype(np.int64)
+    ea, eb, ec = a8.astype(np.int64).sum(1) % q, b8.astype(np.int64).sum(1) % q, c8.sum(1) % q
+    assert np.array_equal(ec, np.array([int(x) * int(y) % q for x, y in zip(ea, eb)], dtype=np.int64))
+
+
+def test_calls_on_two_streams_share_the_workspace_safely(nttx, oracle):
+    """Two device-resident calls on different streams, the second enqueued while the first still runs: the library
+    orders the second behind the first on the device (one workspace per context), so both results are right."""
+    import torch
+    p, L, batch = 469762049, 1 << 18, 48
+    n = L // 2
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    def inputs():
+        x = torch.zeros((batch, L), dtype=torch.int32, device="cuda")
+        x[:, :n] = torch.randint(0, p, (batch, n), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+        return x
+    a1, b1, a2, b2 = inputs(), inputs(), inputs(), inputs()
+    ref1, ref2 = torch.empty_like(a1), torch.empty_like(a1)
+    st0 = torch.cuda.current_stream().cuda_stream
+    nttx.dev_poly_multiply_u32(a1.data_ptr(), b1.data_ptr(), ref1.data_ptr(), n, p, batch, st0)
+    torch.cuda.synchronize()
+    nttx.dev_poly_multiply_u32(a2.data_ptr(), b2.data_ptr(), ref2.data_ptr(), n, p, batch, st0)
+    torch.cuda.synchronize()
+    want = oracle.ntt_compute(a2[3].cpu().numpy().view(np.uint32), b2[3].cpu().numpy().view(np.uint32), p)
+    assert np.array_equal(ref2[3].cpu().numpy().view(np.uint32), want)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        c1, c2 = torch.zeros_like(a1), torch.zeros_like(a1)
+        torch.cuda.synchronize()
+        nttx.dev_poly_multiply_u32(a1.data_ptr(), b1.data_ptr(), c1.data_ptr(), n, p, batch, s1.cuda_stream)
+        nttx.dev_poly_multiply_u32(a2.data_ptr(), b2.data_ptr(), c2.data_ptr(), n, p, batch, s2.cuda_stream)
+        # a host-buffer call in between runs on the null stream and uses the same workspace
+        small = nttx.poly_multiply([1, 5, 5, 4], [4, 1, 5, 2], 4, 7340033, dtype=np.uint64)
+        nttx.dev_poly_multiply_u32(a1.data_ptr(), b1.data_ptr(), c1.data_ptr(), n, p, batch, s1.cuda_stream)
+        torch.cuda.synchronize()
+        assert list(small) == [4, 21, 30, 48, 39, 30, 8]
+        assert torch.equal(c1, ref1) and torch.equal(c2, ref2), rep
+
+
 def test_errors(nttx):
     with pytest.raises(nttx.NttxError):
         nttx.poly_multiply([1], [1], 0, 7340033)
@@ -373,6 +483,38 @@ def test_cpp_harness_binary(oracle, tmp_path):
     for i in range(5):
         got = np.loadtxt(tmp_path / "files" / f"{i}.out", dtype=np.uint64, ndmin=1)
         assert np.array_equal(got, wants[i])
+
+
+def test_cpp_harness_binary_int_flavour(oracle, tmp_path):
+    """nttx_harness_int: the (int, int) course harness of monttry2.cpp:344, 354-400 (poly_multiply(int*, int*, int*,
+    int, int) between fRead and fCheck) on ids 0..3 at the harness sizes; id 4's 51-bit modulus does not fit an int
+    and is reported as an error (the reference reads garbage there)."""
+    import subprocess
+    from oracle import pyoracle as po
+    exe = os.path.join(os.path.dirname(GOLD), "..", "ntt_amd", "csrc", "nttx_harness_int")
+    d = tmp_path / "nttdata"
+    d.mkdir()
+    (tmp_path / "files").mkdir()
+    cases = [([1, 5, 5, 4], [4, 1, 5, 2], 7340033)]
+    for tid in (1, 2, 3, 4):
+        p = P_ID[tid]
+        cases.append((rand(oracle, 131072, 1000 + tid, p), rand(oracle, 131072, 2000 + tid, p), p))
+    wants = []
+    for i, (a, b, p) in enumerate(cases):
+        po.write_in_file(str(d / f"{i}.in"), a, b, p)
+        wants.append(oracle.poly_multiply_crt(a, b, p))
+        po.write_out_file(str(d / f"{i}.out"), wants[-1])
+    env = dict(os.environ, NTT_DATA_DIR=str(d), NTT_OUT_DIR=str(tmp_path / "files"))
+    r = subprocess.run([exe, "0", "3"], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("多项式乘法结果正确") == 4
+    assert r.stdout.count("average latency for n = 131072") == 3 and r.stdout.count("(us)") == 4
+    for i in range(4):
+        got = np.loadtxt(tmp_path / "files" / f"{i}.out", dtype=np.uint64, ndmin=1)
+        assert np.array_equal(got, wants[i])
+    assert open(tmp_path / "files" / "0.out").read() == open(os.path.join(GOLD, "0.out")).read()
+    r = subprocess.run([exe, "4", "4"], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 1 and "does not fit" in r.stderr
 
 
 @pytest.mark.parametrize("n", (131072, 100003, 70000, 65537))

@@ -42,7 +42,7 @@ for r in csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel
 fetch, write, sq, sq2 = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), pmc("pmc_sq2")
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 kind = {"col_kernel<9, false": "col_fwd", "row_mul9_kernel": "row_mul", "col_kernel<9, true": "col_inv"}
-traffic = {}
+traffic, valu_insts = {}, {}
 lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 200 --warmup 50 --no-cpu` (batch 256, L = 2^18, p = 469762049)", "",
          "Kernel trace (`rocprofv3 --kernel-trace --stats`):", "",
          "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
@@ -54,10 +54,11 @@ lines += ["", "Counters (one `--pmc` pass each; values are per launch, mean over
 for n, c, a, *_ in stats:
     f, w = mean(fetch[n]["FETCH_SIZE"]), mean(write[n]["WRITE_SIZE"])
     hbm = (2 * f + w) * 1024
+    s, s2 = sq[n], sq2[n]
     for k, v in kind.items():
         if n.startswith(k):
             traffic[v] = hbm
-    s, s2 = sq[n], sq2[n]
+            valu_insts[v] = mean(s["SQ_INSTS_VALU"])
     lines.append(f"| `{n}` | {f:.0f} | {w:.0f} | {hbm/1e6:.1f} MB | {mean(s['SQ_INSTS_VALU'])/1e6:.2f} M | {mean(s['SQ_INSTS_LDS'])/1e6:.2f} M | "
                  f"{mean(s['SQ_LDS_BANK_CONFLICT'])/1e6:.2f} M / {mean(s['SQ_LDS_IDX_ACTIVE'])/1e6:.2f} M | {mean(s['SQ_WAVE_CYCLES'])/1e6:.1f} M | "
                  f"{mean(s2['SQ_WAIT_ANY'])/1e6:.1f} M | {mean(s2['SQ_WAIT_INST_ANY'])/1e6:.1f} M | {mean(s2['GRBM_GUI_ACTIVE'])/8/1e3:.1f} k cycles |")
@@ -69,5 +70,12 @@ for n, c, a, *_ in stats:
         lines.append(f"- `{n}`: effective clock {cyc / (a * 1e-9) / 1e9:.2f} GHz; VALU issue share ≈ {valu * 4.6 / 1024 / cyc * 100:.0f} % of kernel cycles; "
                      f"HBM {traffic.get([v for k, v in kind.items() if n.startswith(k)][0], float('nan')) / (a * 1e-9) / 1e12:.2f} TB/s")
 open(os.path.join("profiles", f"{tag}_rocprof.md"), "w").write("\n".join(lines) + "\n")
-json.dump(traffic, open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
+# the records bench.py quotes: tagged with a hash of the kernel sources, refused there once the kernels change
+sys.path.insert(0, os.getcwd())
+from bench import kernel_source_tag  # noqa: E402
+meta = {"kernel_source_tag": kernel_source_tag(), "measured_by": f"tools/prof.sh {tag} (bench.py --steps 200 --warmup 50, batch 256)"}
+json.dump(dict(meta, what="HBM bytes per launch: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes", kernels=traffic),
+          open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
+json.dump(dict(meta, what="SQ_INSTS_VALU per launch (wave-level vector instructions)", kernels=valu_insts),
+          open(os.path.join("profiles", "valu.json"), "w"), indent=1)
 print("\n".join(lines))
