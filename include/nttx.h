@@ -34,6 +34,7 @@ extern "C" {
 #define NTTX_ERANGE (-2)   /* exact result not representable: n*(p-1)^2 >= product of CRT primes, or length unsupported */
 #define NTTX_EDEVICE (-3)  /* HIP runtime failure */
 #define NTTX_ENOINIT (-4)  /* nttx_init has not been called */
+#define NTTX_ENOTREADY (-5) /* a call that may not allocate found no tables for its modulus and length */
 
 /* Which arithmetic path a (p, n) pair takes. */
 #define NTTX_PATH_DIRECT32 0 /* one NTT modulo p itself: p < 2^31 prime, 2^k | p-1 (monttry2.cpp get_result) */
@@ -112,6 +113,20 @@ int nttx_dev_negacyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c
  * that take more than one pass (half the input traffic of the cyclic call).  Asynchronous on `stream`. */
 int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch,
                                void *stream);
+
+/* nttx_dev_poly_multiply_u32 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference, which allocates its vectors
+ * inside every product (main.cc:286-298).  Same arguments, results and stream semantics, but the two transformed
+ * copies go to a fixed scratch array inside the library (2 x 16 MiB of device memory per GPU, held until the process
+ * ends) instead of hipMalloc'ed workspace, and the call makes no hipMalloc / hipFree and creates no event:
+ *  - batch * len (len = smallest power of two >= 2n) may not exceed 2^22 words: NTTX_ERANGE beyond that;
+ *  - the tables of (p, len) must exist already, i.e. nttx_dev_poly_multiply_u32 has run once with this modulus and
+ *    length at set-up: NTTX_ENOTREADY otherwise (building tables allocates);
+ *  - every call on a GPU shares that GPU's scratch array and the library does not order such calls against each
+ *    other: two calls in flight at once on one GPU (different streams) race; calls on one stream are safe;
+ *  - per-kernel event timing (nttx_profile_enable) does not cover this entry point. */
+int nttx_dev_poly_multiply_u32_static(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch,
+                                      void *stream);
 
 /* d_ab[b][0..2n-2] = a*b mod p through the 4-prime CRT path; d_a, d_b are [batch][n] u64,
  * d_ab is [batch][2n-1] u64, all device memory.  Asynchronous on `stream`. */

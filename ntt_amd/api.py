@@ -35,6 +35,7 @@ _SIGS = [
     ("nttx_dev_cyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_negacyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_poly_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
+    ("nttx_dev_poly_multiply_u32_static", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_crt_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_dev_ntt_u32", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_crt_prime", C.c_int, [C.c_int, _u32p]),
@@ -211,6 +212,11 @@ def dev_negacyclic_multiply_u32(d_a: int, d_b: int, d_c: int, length: int, p: in
 def dev_poly_multiply_u32(d_a: int, d_b: int, d_c: int, n: int, p: int, batch: int, stream: int = 0):
     """Linear product of zero-padded [batch][len] device arrays (len = pow2 >= 2n)."""
     _check(lib().nttx_dev_poly_multiply_u32(d_a, d_b, d_c, n, p, batch, stream))
+
+
+def dev_poly_multiply_u32_static(d_a: int, d_b: int, d_c: int, n: int, p: int, batch: int, stream: int = 0):
+    """dev_poly_multiply_u32 without any device allocation (fixed scratch inside the library; batch*len <= 2^22)."""
+    _check(lib().nttx_dev_poly_multiply_u32_static(d_a, d_b, d_c, n, p, batch, stream))
 
 
 def dev_crt_multiply_u64(d_a: int, d_b: int, d_ab: int, n: int, p: int, batch: int, stream: int = 0):

@@ -31,6 +31,13 @@ namespace nttx {
 // 2^21 | p-1, so four-prime products support lengths up to 2^21.
 static const uint32_t kCrtPrimes[4] = {469762049u, 998244353u, 1004535809u, 1224736769u};
 
+// Scratch of the entry point that allocates nothing (nttx_dev_poly_multiply_u32_static): the two transformed copies
+// that the other entry points keep in hipMalloc'ed workspace.  One copy of the array per GPU the library runs on, held
+// until the process ends.  Host code never uses the array's name as an address: nttx_init asks the runtime for the
+// device address (hipGetSymbolAddress) and the kernels get that pointer as an argument.
+constexpr long long kStaticWords = 1ll << 22;            // words per copy: batch * length may not exceed this (16 MiB)
+static __device__ __align__(256) uint32_t g_static_scratch[2 * kStaticWords];
+
 static thread_local std::string g_err;
 static int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -181,6 +188,7 @@ struct Context {
   Engine64 *e64 = nullptr;  // plans and workspace of the 64-bit-lane direct path
   // stream of the last call that touched the workspace, and the event that orders the next stream behind it
   hipStream_t last_stream = nullptr; bool have_last = false; hipEvent_t ws_event = nullptr;
+  uint32_t *static_ws = nullptr;   // device address of g_static_scratch on this context's GPU
 };
 static Context *g_ctx = nullptr;
 static std::mutex g_init_mu;
@@ -412,9 +420,11 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 // (the zero padding of a linear product, main.cc:280-281); needs nvalid <= len/2 to take effect.
 // psi_in / psi_out (one- and two-pass plans only): the product becomes the negacyclic one, a and b multiplied by
 // psi_in[i] as the first pass reads them and c by psi_out[i] as the last pass writes it
+// ws != nullptr: the two transformed copies go to ws[0 .. batch*len) and ws[batch*len .. 2*batch*len) instead of the
+// context's grow-only workspace (the caller has checked the size), and nothing is allocated
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
                                hipStream_t st, long long nvalid = 0, const uint32_t *psi_in = nullptr,
-                               const uint32_t *psi_out = nullptr) {
+                               const uint32_t *psi_out = nullptr, uint32_t *ws = nullptr) {
   const long long len = 1ll << pl->logL;
   if (psi_in && pl->npass > 2) return fail(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
   if (pl->npass == 1) {
@@ -427,9 +437,12 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
   // groups, or issuing groups on two streams so column and row passes overlap, both measured slower
   // on MI355X: short launches lose more than residency or overlap wins.)
   const size_t wsz = (size_t)batch * len * 4;
-  if (int rc = cx->wa.ensure(wsz)) return rc;
-  if (int rc = cx->wb.ensure(wsz)) return rc;
-  uint32_t *wa = cx->wa.as<uint32_t>(), *wb = cx->wb.as<uint32_t>();
+  uint32_t *wa = ws, *wb = ws ? ws + (size_t)batch * len : nullptr;
+  if (!ws) {
+    if (int rc = cx->wa.ensure(wsz)) return rc;
+    if (int rc = cx->wb.ensure(wsz)) return rc;
+    wa = cx->wa.as<uint32_t>(); wb = cx->wb.as<uint32_t>();
+  }
   const int ncol = pl->npass - 1;
   int logN = pl->logL;
   for (int lv = 0; lv < ncol; ++lv) {           // forward column passes on a and b
@@ -789,6 +802,9 @@ int nttx_init(int device) {
   g_ctx->device = device;
   g_ctx->e64 = engine64_create();
   HIPCHK(hipEventCreateWithFlags(&g_ctx->ws_event, hipEventDisableTiming));
+  // the static scratch: every GPU holds its own copy of the array at its own address, so the address is asked for
+  // with this context's device current, once per context
+  HIPCHK(hipGetSymbolAddress((void **)&g_ctx->static_ws, HIP_SYMBOL(g_static_scratch)));
   (void)crt_const();
   return 0;
 }
@@ -892,6 +908,28 @@ int nttx_dev_poly_multiply_u32(const void *d_a, const void *d_b, void *d_c, int 
   Plan *pl;
   if (int rc = get_plan(cx, p, log2_ceil_len(n), false, &pl)) return rc;
   return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch, (hipStream_t)stream, n);
+}
+
+int nttx_dev_poly_multiply_u32_static(const void *d_a, const void *d_b, void *d_c, int n, uint32_t p, int batch, void *stream) {
+  NTTX_ENTER();
+  if (!d_a || !d_b || !d_c || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
+  const int logL = log2_ceil_len(n);
+  const long long words = (long long)batch << logL;
+  if (logL > 22 || words > kStaticWords)
+    return fail(NTTX_ERANGE, "batch %d x length 2^%d = %lld words exceeds the static scratch of %lld words per copy; "
+                "use nttx_dev_poly_multiply_u32", batch, logL, words, kStaticWords);
+  auto it = cx->plans.find(std::make_tuple(p, logL, false));
+  if (it == cx->plans.end())
+    return fail(NTTX_ENOTREADY, "no tables yet for modulus %u and length 2^%d: building them allocates, so call "
+                "nttx_dev_poly_multiply_u32 once with this modulus and length at set-up", p, logL);
+  if (!cx->static_ws) return fail(NTTX_EDEVICE, "static scratch address unknown");
+  // no per-kernel event timing on this path (event creation allocates); the setting is restored afterwards
+  const bool prof_was = cx->prof.on;
+  cx->prof.on = false;
+  const int rc = dev_cyclic_multiply(cx, it->second.get(), (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch,
+                                     (hipStream_t)stream, n, nullptr, nullptr, cx->static_ws);
+  cx->prof.on = prof_was;
+  return rc;
 }
 
 int nttx_dev_crt_multiply_u64(const void *d_a, const void *d_b, void *d_ab, int n, uint64_t p, int batch, void *stream) {
