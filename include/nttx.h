@@ -53,6 +53,13 @@ int nttx_init(int device);
 void nttx_shutdown(void);
 const char *nttx_last_error(void);
 
+/* Page-locked host memory for long-lived buffers (the harness's arrays a, b, ab: globals in main.cc:228 /
+ * monttry2.cpp:352).  Optional: the host-buffer entry points below accept any host memory, but move page-locked
+ * buffers by DMA at PCIe speed instead of through the runtime's staging of pageable memory.  Returns NULL on failure
+ * (nttx_last_error() says why); needs nttx_init; release with nttx_host_free before nttx_shutdown. */
+void *nttx_host_alloc(size_t bytes);
+void nttx_host_free(void *ptr);
+
 /* Path that nttx_poly_multiply_u64 / _i32 will take for this modulus and length. */
 int nttx_path_for(uint64_t p, int n);
 

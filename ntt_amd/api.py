@@ -23,6 +23,8 @@ _SIGS = [
     ("nttx_init", C.c_int, [C.c_int]),
     ("nttx_shutdown", None, []),
     ("nttx_last_error", C.c_char_p, []),
+    ("nttx_host_alloc", C.c_void_p, [C.c_size_t]),
+    ("nttx_host_free", None, [C.c_void_p]),
     ("nttx_path_for", C.c_int, [C.c_uint64, C.c_int]),
     ("nttx_poly_multiply_i32", C.c_int, [_i32p, _i32p, _i32p, C.c_int, C.c_int32]),
     ("nttx_poly_multiply_u64", C.c_int, [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]),
@@ -104,6 +106,22 @@ def init(device: int = 0):
 def shutdown():
     if _lib is not None:
         _lib.nttx_shutdown()
+
+
+def host_alloc(count: int, dtype):
+    """A page-locked numpy array of `count` elements (host-buffer calls move it by DMA); release with host_free."""
+    dt = np.dtype(dtype)
+    ptr = lib().nttx_host_alloc(max(1, count) * dt.itemsize)
+    if not ptr:
+        raise NttxError(-3, lib().nttx_last_error().decode())
+    buf = (C.c_char * (count * dt.itemsize)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dt, count=count)
+    arr.flags.writeable = True
+    return arr
+
+
+def host_free(arr):
+    lib().nttx_host_free(arr.ctypes.data)
 
 
 def path_for(p: int, n: int) -> int:

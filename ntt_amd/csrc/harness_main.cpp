@@ -64,7 +64,23 @@ static bool next_u64(const char *&s, uint64_t &v) {
 }
 
 // n p a[0..n) b[0..n)   (fRead, main.cc:78-95)
-static bool fRead(std::vector<coef_t> &a, std::vector<coef_t> &b, int *n, mod_t *p, int id) {
+// The arrays a, b, ab (globals of 300000 words in main.cc:228 / monttry2.cpp:352) are page-locked buffers here, sized
+// per test: the library then moves them by DMA at PCIe speed.
+struct HostArray {
+  coef_t *ptr = nullptr; size_t count = 0;
+  bool resize(size_t n) {
+    if (ptr) nttx_host_free(ptr);
+    count = n;
+    ptr = static_cast<coef_t *>(nttx_host_alloc((n ? n : 1) * sizeof(coef_t)));
+    return ptr != nullptr;
+  }
+  ~HostArray() { if (ptr) nttx_host_free(ptr); }
+  coef_t &operator[](size_t i) { return ptr[i]; }
+  const coef_t &operator[](size_t i) const { return ptr[i]; }
+  coef_t *data() { return ptr; }
+};
+
+static bool fRead(HostArray &a, HostArray &b, int *n, mod_t *p, int id) {
   std::vector<char> buf;
   if (!slurp(data_dir() + "/" + std::to_string(id) + ".in", buf)) return false;
   const char *s = buf.data();
@@ -78,15 +94,14 @@ static bool fRead(std::vector<coef_t> &a, std::vector<coef_t> &b, int *n, mod_t 
 #endif
   *n = (int)nn;
   *p = (mod_t)pp;
-  a.resize(nn);
-  b.resize(nn);
+  if (!a.resize(nn) || !b.resize(nn)) { fprintf(stderr, "%s\n", nttx_last_error()); return false; }
   for (uint64_t i = 0; i < nn; ++i) { if (!next_u64(s, x)) return false; a[i] = (coef_t)x; }
   for (uint64_t i = 0; i < nn; ++i) { if (!next_u64(s, x)) return false; b[i] = (coef_t)x; }
   return true;
 }
 
 // 2n-1 lines (fWrite, main.cc:97-109)
-static void fWrite(const std::vector<coef_t> &ab, int n, int id) {
+static void fWrite(const HostArray &ab, int n, int id) {
   FILE *f = fopen((out_dir() + "/" + std::to_string(id) + ".out").c_str(), "w");
   if (!f) return;
   std::string text;
@@ -101,7 +116,7 @@ static void fWrite(const std::vector<coef_t> &ab, int n, int id) {
 }
 
 // compare with <id>.out (fCheck, main.cc:111-128); also returns the verdict
-static bool fCheck(const std::vector<coef_t> &ab, int n, int id) {
+static bool fCheck(const HostArray &ab, int n, int id) {
   std::vector<char> buf;
   bool ok = slurp(data_dir() + "/" + std::to_string(id) + ".out", buf);
   const char *s = ok ? buf.data() : "";
@@ -141,7 +156,7 @@ int main(int argc, char **argv) {
   printf("nttx: MI355X HIP engine, device %d\n", dv ? atoi(dv) : 0);
   bool all_ok = true;
   for (int id = test_begin; id <= test_end; ++id) {
-    std::vector<coef_t> a, b;
+    HostArray a, b, ab;
     int n_ = 0;
     mod_t p_ = 0;
     if (!fRead(a, b, &n_, &p_, id)) {
@@ -149,7 +164,7 @@ int main(int argc, char **argv) {
       all_ok = false;
       continue;
     }
-    std::vector<coef_t> ab((size_t)2 * n_);
+    if (!ab.resize((size_t)2 * n_)) { fprintf(stderr, "%s\n", nttx_last_error()); return 2; }
     auto t0 = std::chrono::high_resolution_clock::now();
     poly_multiply(a.data(), b.data(), ab.data(), n_, p_);
     auto t1 = std::chrono::high_resolution_clock::now();

@@ -45,8 +45,10 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
-  return fail(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+// (a failed call also leaves its code in the runtime's last-error slot; it is cleared here so that a later launch
+// check does not report it a second time)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+  return fail(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 // ---- grow-only device buffer ----------------------------------------------------------
 struct DevBuf {
@@ -327,7 +329,11 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
       if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((row_mul9_kernel<1, true, true>), grid, dim3(WG), 0, st, A);
       else hipLaunchKernelGGL((row_mul9_kernel<H, true, true>), grid, dim3(WG), 0, st, A);
     } else if (H == 9 && signed_rows(A.ctx.p)) {
+      // NTTX_ROW9_PROBE=1 / 2: the measurement builds of this kernel (one more LDS trip / 24 DPP moves per vector)
+      static const int probe = env_int("NTTX_ROW9_PROBE", 0);
       if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<1, true>), grid, dim3(WG), 0, st, A);
+      else if (probe == 1) hipLaunchKernelGGL((row_mul9_kernel<1, false, false, 1>), grid, dim3(WG), 0, st, A);
+      else if (probe == 2) hipLaunchKernelGGL((row_mul9_kernel<1, false, false, 2>), grid, dim3(WG), 0, st, A);
       else hipLaunchKernelGGL((row_mul9_kernel<1, false>), grid, dim3(WG), 0, st, A);
     } else if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), grid, dim3(WG), 0, st, A);
     else hipLaunchKernelGGL((row_mul9_kernel<H, false>), grid, dim3(WG), 0, st, A);
@@ -826,6 +832,22 @@ void nttx_shutdown(void) {
   g_ctx = nullptr;
 }
 
+void *nttx_host_alloc(size_t bytes) {
+  std::lock_guard<std::mutex> lock_(g_init_mu);
+  if (!g_ctx) { (void)fail(NTTX_ENOINIT, "nttx_init has not been called"); return nullptr; }
+  void *q = nullptr;
+  if (bytes == 0 || hipSetDevice(g_ctx->device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)fail(NTTX_EDEVICE, "page-locked allocation of %zu bytes failed", bytes);
+    return nullptr;
+  }
+  return q;
+}
+
+void nttx_host_free(void *ptr) {
+  if (ptr) (void)hipHostFree(ptr);
+}
+
 int nttx_path_for(uint64_t p, int n) {
   if (n <= 0 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
   const int k = log2_ceil_len(n);
@@ -1001,9 +1023,10 @@ int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse) {
   NTTX_ENTER_ON(nullptr);
   if (!x || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two");
   if (int rc = cx->in_a.ensure((size_t)len * 4)) return rc;
-  HIPCHK(hipMemcpy(cx->in_a.ptr, x, (size_t)len * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(cx->in_a.ptr, x, (size_t)len * 4, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_ntt_impl(cx, cx->in_a.as<uint32_t>(), len, p, inverse, 0, 1, nullptr)) return rc;
-  HIPCHK(hipMemcpy(x, cx->in_a.ptr, (size_t)len * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(x, cx->in_a.ptr, (size_t)len * 4, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1017,10 +1040,11 @@ int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, 
   if (int rc = cx->pa.ensure(bytes)) return rc;
   if (int rc = cx->pb.ensure(bytes)) return rc;
   if (int rc = cx->pc.ensure(bytes)) return rc;
-  HIPCHK(hipMemcpy(cx->pa.ptr, a, bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(cx->pb.ptr, b, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(cx->pa.ptr, a, bytes, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(cx->pb.ptr, b, bytes, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr)) return rc;
-  HIPCHK(hipMemcpy(c, cx->pc.ptr, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(c, cx->pc.ptr, bytes, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1035,17 +1059,21 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
   for (int k = 0; k < 4; ++k) {
     if (!res[k]) return fail(NTTX_EINVAL, "null residue vector");
     uint32_t *d = cx->pc.as<uint32_t>() + (size_t)k * len;
-    HIPCHK(hipMemcpy(d, res[k], bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(d, res[k], bytes, hipMemcpyHostToDevice, nullptr));
     A.res[k] = d;
   }
   A.out = cx->outb.as<uint64_t>(); A.nout = nout; A.len = len; A.batch = 1;
   set_vec(A);
   hipLaunchKernelGGL(crt_kernel, ew_grid2(nout, 1), dim3(256), 0, 0, A);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
+// Host-buffer entry points: the copies in and out are enqueued on the null stream like the kernels between them and the
+// call waits once, after the copy back (page-locked buffers then move by DMA back to back; pageable ones are staged by
+// the runtime, which keeps the caller's buffers safe to reuse on return either way).
 // shared body of the host-buffer direct path: raw u32 coefficients [batch][n] -> [batch][2n-1]
 static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch) {
   const int logL = log2_ceil_len(n);
@@ -1060,8 +1088,8 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)batch * nout * 4)) return rc;
-  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   {
     PadArgs P{}; P.src[0] = cx->in_a.as<uint32_t>(); P.src[1] = cx->in_b.as<uint32_t>();
     P.dst[0] = cx->pa.as<uint32_t>(); P.dst[1] = cx->pb.as<uint32_t>(); P.ctx = pl->ctx; P.n = n; P.len = (int)len;
@@ -1073,7 +1101,8 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   const long long tout = (long long)batch * nout;
   hipLaunchKernelGGL((unpad_kernel<uint32_t>), ew_grid2(nout, batch), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len, batch);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)tout * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)tout * 4, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1104,10 +1133,11 @@ int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *a
   if (int rc = cx->in_a.ensure(raw)) return rc;
   if (int rc = cx->in_b.ensure(raw)) return rc;
   if (int rc = cx->outb.ensure(nout * 8)) return rc;
-  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_crt_multiply(cx, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->outb.as<uint64_t>(), n, p, 1, nullptr)) return rc;
-  HIPCHK(hipMemcpy(ab, cx->outb.ptr, nout * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, nout * 8, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1125,15 +1155,16 @@ int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
-  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   const ProfHook64 ph = prof_hook(cx);
   if (int rc = fail_from64(engine64_pad(cx->e64, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->pa.as<uint64_t>(),
                                         cx->pb.as<uint64_t>(), n, logL, p, 1, nullptr))) return rc;
   if (int rc = fail_from64(engine64_cyclic_multiply(cx->e64, cx->pa.as<uint64_t>(), cx->pb.as<uint64_t>(), cx->pc.as<uint64_t>(),
                                                     logL, p, 1, n, nullptr, &ph))) return rc;
   if (int rc = fail_from64(engine64_unpad(cx->pc.as<uint64_t>(), cx->outb.as<uint64_t>(), nout, logL, 1, nullptr))) return rc;
-  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1188,8 +1219,8 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
-  HIPCHK(hipMemcpy(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   {
     SplitArgs S{}; S.src[0] = cx->in_a.as<uint64_t>(); S.src[1] = cx->in_b.as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len;
     S.zfill = pl->npass == 1 ? (int)len : n; S.batch = 1; S.pmod = 0;
@@ -1201,7 +1232,8 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr, n)) return rc;
   hipLaunchKernelGGL((unpad_kernel<uint64_t>), ew_grid2(nout, 1), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len, 1);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 

@@ -31,8 +31,8 @@ static int fail64(int code, const char *fmt, ...) {
   return code;
 }
 const char *engine64_error() { return g_err64.c_str(); }
-#define HIPCHK64(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
-  return fail64(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define HIPCHK64(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+  return fail64(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 constexpr int kMaxRow64 = 13, kMinCol64 = 6, kMaxCol64 = 9, kMaxLog64 = 29;
 // Longest row pass for modulus p.  Rows of 2^12 and 2^13 points take one whole workgroup each

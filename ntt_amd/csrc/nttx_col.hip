@@ -23,7 +23,19 @@ constexpr int kMinColLog = 6;
 template <bool INV, int H, bool ZHI, bool FS2>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
-  const long long tiles = A.nblocks << (A.logS - (wide ? 5 : 4));
+  // Few tiles (one product, or a handful): full-line tiles would leave most of the 256 CUs idle while each of the busy
+  // ones works through 16384 points, so 2^9-point passes switch to tiles of 8 or 4 columns with one radix-8 unit per
+  // thread and round, until about 256 workgroups exist (one 2^18-point product: 7.8 -> about 2.5 us per pass).
+  // NTTX_COL_NARROW=0 keeps full-line tiles (A/B measurements), 2 or 3 forces a width.
+  int lc = wide ? 5 : 4;
+  if (wide && logT == 9 && !FS2 && !A.psi) {
+    static const int narrow = env_int("NTTX_COL_NARROW", -1);
+    long long w = (A.nblocks << (A.logS - 5)) * nvec;
+    if (narrow == 2 || narrow == 3) lc = narrow;
+    else if (narrow != 0) while (lc > 2 && w < 192) { --lc; w <<= 1; }
+    if (lc == 4) lc = 3;                       // (the 16-column shape keeps four units per thread: no gain there)
+  }
+  const long long tiles = A.nblocks << (A.logS - lc);
   // workgroups per launch (tuning knobs; any value is correct, workgroups stride over the tiles)
   // Measured on MI355X: one tile per workgroup (the hardware dispatcher refills CUs as workgroups retire,
   // which staggers their load / butterfly / store phases) beats a resident grid striding over the tiles
@@ -53,6 +65,12 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
       case 19: NTTX_COL_CASE(9, 5, 512)   case 20: NTTX_COL_CASE(10, 4, 256)   // 512 threads: the 1024-thread shape has no registers left for the second factor
       default: return colfail(NTTX_ERANGE, "split-table column pass of this size unsupported");
     }
+    if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
+    return 0;
+  }
+  if (lc < 4) {
+    if (lc == 3) { hipLaunchKernelGGL((col_kernel<9, INV, H, 3, 512, ZHI, false>), dim3(grid, 1, nvec), dim3(512), 0, st, A); }
+    else { hipLaunchKernelGGL((col_kernel<9, INV, H, 2, 256, ZHI, false>), dim3(grid, 1, nvec), dim3(256), 0, st, A); }
     if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
     return 0;
   }

@@ -601,7 +601,12 @@ constexpr int ROW9_PAD = 576;  // 512 + 8 pad words per 64
 // CANON: outputs fully reduced (single-pass products); otherwise they are left unreduced for the
 // inverse column pass, which multiplies them by its four-step constants first.
 // TWIST (with CANON): negacyclic product of 512-point vectors, the psi factors applied in registers.
-template <int H, bool CANON, bool TWIST = false>
+// PROBE (measurement builds of the same kernel, results unchanged): what moving a lane's 8 values between lanes costs
+// here, by either mechanism.  1: one more trip of both vectors through the wave-private LDS buffer (8 ds_write_b32 +
+// 8 ds_read_b32 per vector, what each exchange between rounds costs now).  2: 24 DPP moves
+// per vector (8 registers x the three lane distances 8, 16, 32 that a shuffle-based round 2 would cross, at one move
+// per register and distance, its minimum), issued as pairs of row rotations by 8, i.e. the identity.
+template <int H, bool CANON, bool TWIST = false, int PROBE = 0>
 __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A) {
   static_assert(!TWIST || CANON, "the twisted product is a single-pass product");
   __shared__ __attribute__((aligned(16))) uint32_t lds[(WG / 64) * 2 * ROW9_PAD];
@@ -655,6 +660,26 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
     uint32_t a[8], b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a[j] = sa[o2 + 8 * j]; b[j] = sb[o2 + 8 * j]; }
+    if constexpr (PROBE == 1) {
+      // (through the round-1 slots of the lane, whose contents have been consumed; a memory clobber keeps the compiler
+      // from forwarding the stored values)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sa[o1 + 72 * j] = a[j]; sb[o1 + 72 * j] = b[j]; }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a[j] = sa[o1 + 72 * j]; b[j] = sb[o1 + 72 * j]; }
+      asm volatile("" ::: "memory");
+    } else if constexpr (PROBE == 2) {
+      // row_ror:8 (DPP control 0x128) twice is the identity on a row of 16 lanes: 3 such pairs on registers 0..3 and
+      // ... 24 moves per vector in all, every register rotated an even number of times
+      auto ror8 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); };
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] = ror8(ror8(a[j])); b[j] = ror8(ror8(b[j]));
+        if (j < 4) { a[j] = ror8(ror8(a[j])); b[j] = ror8(ror8(b[j])); }
+      }
+    }
     // forward round 2 (32, 16, 8)
     r8_dif<H, false, false, KF, KF>(a, wf2, M);
     r8_dif<H, false, false, KF, KF>(b, wf2, M);
@@ -958,7 +983,10 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
   const long long ntiles = A.nblocks << log_tpb;
   const int j0 = threadIdx.x >> LOG_LPR, c4 = (threadIdx.x & (LPR - 1)) * 4;
 
-  for (int i = threadIdx.x; i < T; i += NTHR) tw[i] = A.tw[i];
+  // LAT: narrow tiles serve launches of few tiles, where one tile's latency is the whole kernel: the four-step factors
+  // are fetched into registers together with the data (inverse) or before the butterflies (forward) instead of when
+  // they are needed, so a tile pays one trip to memory instead of two or three.
+  constexpr bool LAT = (LOGC <= 3) && !FS2 && !TWIST;
 
   auto tile_base = [&](long long t) -> long long {
     const long long blk = t >> log_tpb;
@@ -966,6 +994,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     return (blk << (logS + LOGT)) + (ct << LOGC);
   };
   auto fs_base = [&](long long t) -> long long { return (t & ((1ll << log_tpb) - 1)) << LOGC; };
+  auto fs_load = [&](long long fbase, int j) -> uint4 {
+    return *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
+  };
+  auto fs_apply = [&](uint4 &x, const uint4 &f) {
+    x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
+    x.z = M.mul(V<Arith<H>::KANY>{x.z}, f.z).v; x.w = M.mul(V<Arith<H>::KANY>{x.w}, f.w).v;
+  };
   // x * (four-step factor of row j, columns fbase + c4 .. + 3)
   auto fs_mul = [&](uint4 &x, long long fbase, int j) {
     uint4 f;
@@ -1000,22 +1035,29 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
       return x;
     }
   };
-  // 64-byte tiles: the two halves of a 128-byte line go to workgroups 8 block slots apart, which the
-  // dispatcher places on the same XCD, so that XCD's L2 merges their half-line writes and serves the
-  // second half-line read (a placement heuristic for speed; any placement is correct).
+  // Tiles narrower than a 128-byte line: the 2, 4 or 8 tiles that share a line go to workgroups 8 block slots apart,
+  // which the dispatcher places on the same XCD, so that XCD's L2 merges their partial-line writes and serves the
+  // later partial-line reads (a placement heuristic for speed; any placement is correct).
   auto remap = [&](long long t0) -> long long {
-    if constexpr (LOGC == 4) {
-      if ((t0 | 15) < ntiles) { const long long r = t0 & 15; return (t0 & ~15ll) + ((r & 7) << 1) + (r >> 3); }
+    if constexpr (LOGC < 5) {
+      constexpr int G = 1 << (5 - LOGC), CH = 8 * G;
+      if ((t0 | (CH - 1)) < ntiles) { const long long r = t0 & (CH - 1); return (t0 & ~(long long)(CH - 1)) + (r & 7) * G + (r >> 3); }
     }
     return t0;
   };
   uint4 nx[PERL];
+  uint4 fx[(LAT && INV) ? PERL : 1];   // LAT, inverse: the factors of the pieces in nx
   long long t0 = blockIdx.x;
   if (t0 < ntiles) {
     const long long t = remap(t0), base = tile_base(t);
 #pragma unroll
     for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, t, j0 + k * RSTEP);
+    if constexpr (LAT && INV) {
+#pragma unroll
+      for (int k = 0; k < PERL; ++k) fx[k] = fs_load(fs_base(t), j0 + k * RSTEP);
+    }
   }
+  for (int i = threadIdx.x; i < T; i += NTHR) tw[i] = A.tw[i];   // (after the first tile's loads are in flight)
   for (; t0 < ntiles; t0 += gridDim.x) {
     const long long t = remap(t0);
     const long long gbase = tile_base(t), fbase = fs_base(t);
@@ -1024,7 +1066,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     for (int k = 0; k < PERL; ++k) {
       uint4 x = nx[k];
       const int j = j0 + k * RSTEP;
-      if (INV) fs_mul(x, fbase, j);
+      if constexpr (LAT && INV) fs_apply(x, fx[k]);
+      else if (INV) fs_mul(x, fbase, j);
       if constexpr (TWIST && !INV) {
         const uint4 f = *reinterpret_cast<const uint4 *>(A.psi + fbase + ((long long)j << logS) + c4);
         x.x = M.mul(V<Arith<H>::KANY>{x.x}, f.x).v; x.y = M.mul(V<Arith<H>::KANY>{x.y}, f.y).v;
@@ -1036,6 +1079,15 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
       const long long tn = remap(t0 + gridDim.x), base = tile_base(tn);
 #pragma unroll
       for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, tn, j0 + k * RSTEP);
+      if constexpr (LAT && INV) {
+#pragma unroll
+        for (int k = 0; k < PERL; ++k) fx[k] = fs_load(fs_base(tn), j0 + k * RSTEP);
+      }
+    }
+    uint4 fo[(LAT && !INV) ? PER : 1];   // LAT, forward: this tile's output factors, in flight during the butterflies
+    if constexpr (LAT && !INV) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) fo[k] = fs_load(fbase, j0 + k * RSTEP);
     }
     __syncthreads();
     uint32_t *const vec[1] = {s};
@@ -1049,7 +1101,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     for (int k = 0; k < PER; ++k) {
       const int j = j0 + k * RSTEP;
       uint4 x = *reinterpret_cast<const uint4 *>(s + L::addr(c4, j));
-      if (!INV) fs_mul(x, fbase, j);
+      if constexpr (LAT && !INV) fs_apply(x, fo[k]);
+      else if (!INV) fs_mul(x, fbase, j);
       if constexpr (TWIST && INV) {
         const uint4 f = *reinterpret_cast<const uint4 *>(A.psi + fbase + ((long long)j << logS) + c4);
         x.x = M.canon(M.mul(V<Arith<H>::KI>{x.x}, f.x)); x.y = M.canon(M.mul(V<Arith<H>::KI>{x.y}, f.y));

@@ -356,6 +356,24 @@ def test_calls_on_two_streams_share_the_workspace_safely(nttx, oracle):
         assert torch.equal(c1, ref1) and torch.equal(c2, ref2), rep
 
 
+def test_page_locked_host_buffers(nttx, oracle):
+    """nttx_host_alloc: page-locked arrays for the harness's long-lived a, b, ab; same coefficients as pageable ones."""
+    import ctypes as C
+    u64p = C.POINTER(C.c_uint64)
+    for p, n in ((469762049, 131072), (1337006139375617, 70001), (1000000007, 5000)):
+        a, b, ab = nttx.host_alloc(n, np.uint64), nttx.host_alloc(n, np.uint64), nttx.host_alloc(2 * n - 1, np.uint64)
+        try:
+            a[:], b[:] = rand(oracle, n, 3, p), rand(oracle, n, 4, p)
+            for _ in range(2):
+                ab[:] = 0
+                rc = nttx.lib().nttx_poly_multiply_u64(a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), ab.ctypes.data_as(u64p), n, p)
+                assert rc == 0
+                assert np.array_equal(ab, oracle.poly_multiply_crt(a, b, p)), (p, n)
+        finally:
+            for x in (a, b, ab):
+                nttx.host_free(x)
+
+
 def test_errors(nttx):
     with pytest.raises(nttx.NttxError):
         nttx.poly_multiply([1], [1], 0, 7340033)
