@@ -191,6 +191,10 @@ struct Context {
   // stream of the last call that touched the workspace, and the event that orders the next stream behind it
   hipStream_t last_stream = nullptr; bool have_last = false; hipEvent_t ws_event = nullptr;
   uint32_t *static_ws = nullptr;   // device address of g_static_scratch on this context's GPU
+  // CRT route: the products modulo the second to fourth prime run on these streams beside the first prime's
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+  DevBuf wsx;                      // their transformed copies (the first prime uses wa / wb)
 };
 static Context *g_ctx = nullptr;
 static std::mutex g_init_mu;
@@ -558,6 +562,41 @@ static int log2_ceil_len(int n) {  // main.cc:278-279: smallest power of two >= 
   return k;
 }
 
+// The single-prime products of the CRT route (the reference runs them on one thread per prime, main.cc:306-311 /
+// main_pthread.cc:413-428) run side by side: prime 0 on the caller's stream, the others on side streams forked from it
+// and joined back before the recombination, so the start and the tail of one prime's passes overlap another's.
+// Measured on MI355X at n = 2^17, four primes: 8 products 19.3 -> 17.0 us each, 32: 13.5 -> 12.7, 128: 11.5 -> 11.3,
+// 256: 11.2 -> 11.0; below about 6 products the forks and joins cost more than they win (one product 66 -> 110 us),
+// so those stay on one stream.  NTTX_CRT_STREAMS=0 / 1 forces one stream / side streams (A/B measurements).
+static bool crt_side_by_side(size_t words, int ns, int npass) {
+  static const int mode = env_int("NTTX_CRT_STREAMS", -1);
+  if (ns < 2 || npass < 2 || mode == 0) return false;
+  return mode == 1 || (words >= ((size_t)6 << 18) && words <= ((size_t)512 << 18));
+}
+static int crt_products(Context *cx, Plan *const pl[4], int ns, const uint32_t *pa, const uint32_t *pb, uint32_t *const out[4],
+                        int batch, int n, hipStream_t st) {
+  const long long len = 1ll << pl[0]->logL;
+  const size_t words = (size_t)batch * len;
+  const bool par = crt_side_by_side(words, ns, pl[0]->npass);
+  if (par) {
+    if (int rc = cx->wsx.ensure((size_t)(ns - 1) * 2 * words * 4)) return rc;
+    HIPCHK(hipEventRecord(cx->fork_ev, st));
+    for (int k = 1; k < ns; ++k) HIPCHK(hipStreamWaitEvent(cx->side[k - 1], cx->fork_ev, 0));
+  }
+  for (int k = 0; k < ns; ++k) {
+    hipStream_t sk = (par && k > 0) ? cx->side[k - 1] : st;
+    uint32_t *ws = (par && k > 0) ? cx->wsx.as<uint32_t>() + (size_t)(k - 1) * 2 * words : nullptr;
+    if (int rc = dev_cyclic_multiply(cx, pl[k], pa + (size_t)k * words, pb + (size_t)k * words, out[k], batch, sk, n, nullptr, nullptr, ws)) return rc;
+  }
+  if (par) {
+    for (int k = 1; k < ns; ++k) {
+      HIPCHK(hipEventRecord(cx->join_ev[k - 1], cx->side[k - 1]));
+      HIPCHK(hipStreamWaitEvent(st, cx->join_ev[k - 1], 0));
+    }
+  }
+  return 0;
+}
+
 // d_ab[b][0..2n-2] from u64 device inputs through the CRT path: the reference's four primes
 // (main.cc:245-248), or only three, two or one of them where n*(p-1)^2 stays below their product
 // (three for every modulus below 2^36 at n = 2^17, two below 2^21): fewer transforms, the same
@@ -595,13 +634,9 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
   }
   CrtArgs A{};
   if (int rc = fill_crt_args(A, p, sel, ns)) return rc;
-  for (int k = 0; k < ns; ++k) {
-    const uint32_t *a = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
-    const uint32_t *b = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
-    uint32_t *c = cx->pc.as<uint32_t>() + (size_t)k * batch * len;
-    if (int rc = dev_cyclic_multiply(cx, pl[k], a, b, c, batch, st, n)) return rc;
-    A.res[k] = c;
-  }
+  uint32_t *outs[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < ns; ++k) { outs[k] = cx->pc.as<uint32_t>() + (size_t)k * batch * len; A.res[k] = outs[k]; }
+  if (int rc = crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st)) return rc;
   A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len; A.batch = batch;
   cx->prof.begin(PK_CRT, st);
   set_vec(A);
@@ -640,9 +675,9 @@ static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_
   hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
-  for (int i = 0; i < ns; ++i)
-    if (int rc = dev_cyclic_multiply(cx, pl[i], S.dst[0][i], S.dst[1][i], d_res + (size_t)i * batch * len, batch, st, n)) return rc;
-  return 0;
+  uint32_t *outs[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < ns; ++i) outs[i] = d_res + (size_t)i * batch * len;
+  return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st);
 }
 
 // out[i] = (the integer below M with residues r_k[i]) mod p, i < count (main.cc:323-337 on a slice)
@@ -811,6 +846,11 @@ int nttx_init(int device) {
   // the static scratch: every GPU holds its own copy of the array at its own address, so the address is asked for
   // with this context's device current, once per context
   HIPCHK(hipGetSymbolAddress((void **)&g_ctx->static_ws, HIP_SYMBOL(g_static_scratch)));
+  HIPCHK(hipEventCreateWithFlags(&g_ctx->fork_ev, hipEventDisableTiming));
+  for (int k = 0; k < 3; ++k) {
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx->side[k], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&g_ctx->join_ev[k], hipEventDisableTiming));
+  }
   (void)crt_const();
   return 0;
 }
@@ -826,6 +866,12 @@ void nttx_shutdown(void) {
   engine64_destroy(g_ctx->e64);
   g_ctx->prof.destroy();
   if (g_ctx->ws_event) (void)hipEventDestroy(g_ctx->ws_event);
+  if (g_ctx->fork_ev) (void)hipEventDestroy(g_ctx->fork_ev);
+  for (int k = 0; k < 3; ++k) {
+    if (g_ctx->join_ev[k]) (void)hipEventDestroy(g_ctx->join_ev[k]);
+    if (g_ctx->side[k]) (void)hipStreamDestroy(g_ctx->side[k]);
+  }
+  g_ctx->wsx.release();
   for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
     b->release();
   delete g_ctx;
@@ -904,6 +950,8 @@ int nttx_reserve(int len, int batch, int nprimes) {
     if (int rc = cx->pa.ensure(nprimes * vec)) return rc;
     if (int rc = cx->pb.ensure(nprimes * vec)) return rc;
     if (int rc = cx->pc.ensure(nprimes * vec)) return rc;
+    if (crt_side_by_side((size_t)batch * len, nprimes, 2))
+      if (int rc = cx->wsx.ensure((size_t)(nprimes - 1) * 2 * vec)) return rc;
   }
   return 0;
 }
