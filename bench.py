@@ -139,6 +139,15 @@ def cpu_baseline_main_cc(n, p, reps=80, reps_extra=5, extras=True):
             R.ntt_compute(au, bu, p)
             ts.append((time.perf_counter() - t0) * 1e3)
         single["main.cc ntt_compute_omp, one prime (1 thread)"] = statistics.median(ts)
+        # the same stage-parallel program with its thread handling tuned (oracle/cpu_pool.c: one standing pool and a
+        # barrier per stage instead of 18 create/join rounds per transform; the butterflies are the reference's)
+        for threads in sorted({8, min(cores, 32)}):
+            ts = []
+            for _ in range(reps_extra + 1):
+                t0 = time.perf_counter()
+                O.pool_poly_multiply(a32, b32, p, threads)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            single[f"pooled variant of monttry2.cpp / pthread_normal.cpp ({threads} threads, port)"] = statistics.median(ts[1:])
         out["single_prime_ms_per_mult"] = single
     return out
 
@@ -167,8 +176,15 @@ def cpu_baseline_single_prime(n, p, budget_s=12.0):
         fn()
         ts.append((time.perf_counter() - t0) * 1e3)
     med = statistics.median(ts)
-    return {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "ms_per_mult": med,
-            "sample": f"{what}: {len(ts)} products of n={n} coefficients, p={p}, one after the other, median"}
+    out = {"value": 1000.0 / med, "unit": "poly-mults/s", "cores": cores, "kind": kind, "ms_per_mult": med,
+           "sample": f"{what}: {len(ts)} products of n={n} coefficients, p={p}, one after the other, median"}
+    tp = []
+    for _ in range(6):     # the tuned-thread-handling port of the same program (oracle/cpu_pool.c), a reported extra
+        t0 = time.perf_counter()
+        O.pool_poly_multiply(a, b, p, 8)
+        tp.append((time.perf_counter() - t0) * 1e3)
+    out["pooled_variant_8_threads_ms_per_mult"] = statistics.median(tp[1:])
+    return out
 
 
 def cpu_baseline_long(log_len, p):

@@ -65,6 +65,7 @@ class Oracle:
         L.oracle_poly_multiply_naive_u64.argtypes = [_u64p, _u64p, _u64p, C.c_int, C.c_uint64]
         L.oracle_fill_random.argtypes = [_u64p, C.c_longlong, C.c_uint64, C.c_uint64]
         L.oracle_max_threads.restype = C.c_int
+        L.pool_poly_multiply_mont.argtypes = [_i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int]
 
     # --- Barrett / transform level (main.cc) ---
     def barrett_reduce(self, mod, a):
@@ -151,6 +152,15 @@ class Oracle:
         out = np.empty(count, dtype=np.uint64)
         self.lib.oracle_fill_random(_ptr(out, _u64p), count, seed, p)
         return out
+
+    def pool_poly_multiply(self, a, b, p, threads=8):
+        """cpu_pool.c: monttry2.cpp / pthread_normal.cpp's stage-parallel product on a standing thread pool."""
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        b = np.ascontiguousarray(b, dtype=np.int32)
+        n = len(a)
+        out = np.zeros(2 * n - 1, dtype=np.int32)
+        rc = self.lib.pool_poly_multiply_mont(_ptr(a, _i32p), _ptr(b, _i32p), _ptr(out, _i32p), n, p, threads)
+        return rc, out
 
     def max_threads(self):
         return int(self.lib.oracle_max_threads())
