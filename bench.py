@@ -14,7 +14,7 @@ Workloads (a "step" is one pass of the hot path over one batch of synthetic inpu
             32 products per rank and step (weak scaling)
   batch     4096 independent products of length 2^16 dealt to the ranks, no collective (strong scaling)
   fourstep  ONE product of length 2^24 (--log-len up to 26): one rank runs the single-GPU three-pass plan,
-            N > 1 ranks split the T x S matrix by columns, two all-to-alls per product
+            N > 1 ranks split the T x S matrix by columns, one all-to-all per vector (a, b, product)
             (ntt_amd.distributed.FourStepSharded; strong scaling)
 
 Ranks: under `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is
@@ -295,6 +295,10 @@ class HostStagedComm:
 
     def all_to_all(self, send):
         return self._c.all_to_all(send.cpu()).to(self._dev)
+
+    def all_to_all_start(self, send):
+        from ntt_amd.distributed import _Pending
+        return _Pending(None, self.all_to_all(send))
 
     def all_gather(self, x):
         return self._c.all_gather(x.cpu()).to(self._dev)
@@ -690,7 +694,7 @@ def run_fourstep(R, args):
         else:
             bytes_per_step = {"col_fwd": (2 * 6 + 16) * slab, "row_mul": 12 * slab, "col_inv": (8 + 8) * slab}
             launches = {"col_fwd": 3, "row_mul": 1, "col_inv": 2}
-        par = f"columns split over {R.world} ranks, two all-to-alls per product"
+        par = f"columns split over {R.world} ranks, one all-to-all per vector (a, b, product)"
         exch = int(3 * slab * 4 * (R.world - 1) / R.world)
         cfg_extra = {"log2_t": fs.log_t, "row_passes": rplan}
     elapsed = R.timed(step, args.steps, args.warmup, events=not args.no_events)

@@ -11,7 +11,7 @@ Two workloads have a real exchange step:
 * `FourStepSharded` - one product too long for a single pass structure to stay on one GPU: the
   vector is a T x S matrix split by columns; column passes are local, a transpose (all-to-all)
   turns column slabs into whole rows, the rows are multiplied locally, and the way back mirrors
-  it: two all-to-alls per product (both inputs travel in the first).
+  it: three all-to-alls per product, one per vector (a's is in flight while b's column pass runs).
 
 Independent products need no exchange at all; they are sharded with `sharding.shard_range`.
 
@@ -55,6 +55,18 @@ class TorchComm:
         self._dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
+    def all_to_all_start(self, send):
+        """The same exchange, started and not waited for: returns a handle whose wait() gives recv.  Over RCCL the
+        exchange runs on the communicator's own stream behind the work already enqueued on the current stream, so
+        kernels launched after this call overlap with it."""
+        import torch
+        send = send.contiguous()
+        if send.shape[0] != self.world:
+            raise ValueError("leading dimension must equal the group size")
+        recv = torch.empty_like(send)
+        work = self._dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return _Pending(work, recv, send)
+
     def all_gather(self, x):
         import torch
         x = x.contiguous()
@@ -78,6 +90,19 @@ class TorchComm:
             if self.rank in members:
                 mine = TorchComm(g, [self.ranks[m] for m in members])
         return mine
+
+
+class _Pending:
+    """An exchange in flight: wait() blocks the current stream (not the host, over RCCL) until recv is complete."""
+
+    def __init__(self, work, recv, keep=None):
+        self._work, self._recv, self._keep = work, recv, keep      # keep: the send buffer must outlive the exchange
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._recv
 
 
 class _ThreadWorld:
@@ -137,6 +162,9 @@ class ThreadComm:
             torch.cuda.current_stream().synchronize()
         seen = self._exchange(send.contiguous())
         return torch.stack([seen[q][self.rank] for q in range(self.world)])
+
+    def all_to_all_start(self, send):
+        return _Pending(None, self.all_to_all(send))
 
     def all_gather(self, x):
         import torch
@@ -315,15 +343,14 @@ class FourStepSharded:
     def place_slab(self, vec, slab):
         vec.view(self.T, self.S)[:, self.col0: self.col0 + self.cols] = slab
 
-    def _to_rows(self, xs):
-        """Column slabs of several vectors -> whole rows of each, in ONE exchange."""
-        g = self.comm.world
-        if g == 1:
-            return list(xs)
-        import torch
-        send = torch.stack([x.view(g, self.rows, self.cols) for x in xs], dim=1)   # [dest][vector][rows][cols]
-        recv = self.comm.all_to_all(send)                                           # [source][vector][rows][cols]
-        return [recv[:, v].permute(1, 0, 2).reshape(self.rows, self.S) for v in range(len(xs))]
+    def _send_rows(self, x):
+        """Start the exchange that turns this rank's column slab of one vector into whole rows.  The slab is row-major,
+        so its [dest][rows][cols] view is the send buffer as it stands: no packing copy."""
+        return self.comm.all_to_all_start(x.view(self.comm.world, self.rows, self.cols))
+
+    def _rows_of(self, pending):
+        recv = pending.wait()                                                    # [source][rows][cols]
+        return recv.permute(1, 0, 2).reshape(self.rows, self.S)                  # (one copy: rows become contiguous)
 
     def _to_slab(self, y):
         g = self.comm.world
@@ -337,9 +364,17 @@ class FourStepSharded:
         2^(log_len-1) on (a linear product), so the upper half of the rows is not read.
         Returns this rank's slab of the product."""
         e, L, t, p = self.engine, self.log_len, self.log_t, self.p
-        e.colpass(xa, L, t, self.col0, p, False, zero_hi)
-        e.colpass(xb, L, t, self.col0, p, False, zero_hi)
-        ya, yb = self._to_rows([xa, xb])
+        if self.comm.world == 1:
+            e.colpass(xa, L, t, self.col0, p, False, zero_hi)
+            e.colpass(xb, L, t, self.col0, p, False, zero_hi)
+            ya, yb = xa, xb
+        else:
+            # a's exchange is in flight while b's column pass runs
+            e.colpass(xa, L, t, self.col0, p, False, zero_hi)
+            pa = self._send_rows(xa)
+            e.colpass(xb, L, t, self.col0, p, False, zero_hi)
+            pb = self._send_rows(xb)
+            ya, yb = self._rows_of(pa), self._rows_of(pb)
         yc = e.cyclic_multiply(ya.contiguous(), yb.contiguous(), p)
         xc = self._to_slab(yc).contiguous()
         e.colpass(xc, L, t, self.col0, p, True)

@@ -156,6 +156,13 @@ def test_exchange_steps_in_process_ranks(oracle):
             if pr == 0:
                 seen[lo:hi] += 1
         assert (seen == 1).all()
+    # beyond the exactness bound n*(p-1)^2 < M the sharded product refuses like the single-GPU entry point (NTTX_ERANGE)
+    import pytest
+    from ntt_amd import NttxError
+    big = (1 << 61) - 1
+    with pytest.raises(NttxError) as err:
+        ThreadComm.run(1, lambda comm: _run_crt(comm, oracle, a % np.uint64(big), b % np.uint64(big), n, big, True))
+    assert err.value.code == -2
     for p, log_len, log_t, world, linear in ((998244353, 12, 6, 4, False), (1224736769, 13, 7, 2, True), (469762049, 12, 6, 1, True)):
         fa, fb, fwant = _fourstep_case(oracle, log_len, p, linear)
         outs = ThreadComm.run(world, lambda comm: _run_fourstep(comm, oracle, fa, fb, log_len, log_t, p, linear))
