@@ -201,6 +201,15 @@ int nttx_dev_crt_recombine_u64(const void *d_r0, const void *d_r1, const void *d
 int nttx_dev_colpass_u32(void *d_x, int log_len, int log_t, long long col0, int cols, uint32_t p, int inverse,
                          int zero_hi, void *stream);
 
+/* Cyclic products of `rows` vectors of length len held in the layout an all-to-all between processes leaves them in:
+ * d_a, d_b, d_c are [pieces][rows][len / pieces] u32 arrays, vector r being the concatenation of its pieces
+ * (piece q = what process q sent, resp. will receive).  Same products as nttx_dev_cyclic_multiply_u32 on [rows][len]
+ * arrays, without the two reordering copies around it: the first pass reads the pieces, the last one writes them.
+ * len = 2^15 .. 2^17, pieces a power of two up to len / 512.  Part of the column-split product above; no counterpart
+ * in the reference. */
+int nttx_dev_cyclic_multiply_pieces_u32(const void *d_a, const void *d_b, void *d_c, int len, int pieces, int rows, uint32_t p,
+                                        void *stream);
+
 /* Pre-size the internal workspace so that later device-resident calls allocate nothing. */
 int nttx_reserve(int len, int batch, int nprimes);
 int nttx_reserve_u64(int len, int batch);   /* same for the 64-bit-lane direct path */

@@ -35,6 +35,7 @@ _SIGS = [
     ("nttx_cyclic_multiply_u32", C.c_int, [_u32p, _u32p, _u32p, C.c_int, C.c_uint32]),
     ("nttx_crt_combine_u64", C.c_int, [C.POINTER(_u32p), _u64p, C.c_int, C.c_int, C.c_uint64]),
     ("nttx_dev_cyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
+    ("nttx_dev_cyclic_multiply_pieces_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]),
     ("nttx_dev_negacyclic_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_poly_multiply_u32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
     ("nttx_dev_poly_multiply_u32_static", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
@@ -220,6 +221,11 @@ def crt_combine(residues, nout: int, p: int):
 # ---- device-resident calls: arguments are raw device pointers (e.g. torch tensor.data_ptr()) ----
 def dev_cyclic_multiply_u32(d_a: int, d_b: int, d_c: int, length: int, p: int, batch: int, stream: int = 0):
     _check(lib().nttx_dev_cyclic_multiply_u32(d_a, d_b, d_c, length, p, batch, stream))
+
+
+def dev_cyclic_multiply_pieces_u32(d_a: int, d_b: int, d_c: int, length: int, pieces: int, rows: int, p: int, stream: int = 0):
+    """Cyclic products of [pieces][rows][length / pieces] arrays (the layout an all-to-all leaves rows in)."""
+    _check(lib().nttx_dev_cyclic_multiply_pieces_u32(d_a, d_b, d_c, length, pieces, rows, p, stream))
 
 
 def dev_negacyclic_multiply_u32(d_a: int, d_b: int, d_c: int, length: int, p: int, batch: int, stream: int = 0):

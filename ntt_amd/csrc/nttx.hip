@@ -434,9 +434,19 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 // context's grow-only workspace (the caller has checked the size), and nothing is allocated
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
                                hipStream_t st, long long nvalid = 0, const uint32_t *psi_in = nullptr,
-                               const uint32_t *psi_out = nullptr, uint32_t *ws = nullptr) {
+                               const uint32_t *psi_out = nullptr, uint32_t *ws = nullptr, int pieces = 0) {
   const long long len = 1ll << pl->logL;
   if (psi_in && pl->npass > 2) return fail(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
+  // pieces > 0: a, b and c are [pieces][batch][len / pieces] arrays (vector r = the concatenation of its pieces), the
+  // layout in which an all-to-all between processes delivers rows and takes them back: the first forward pass reads
+  // it and the last inverse pass writes it, so no reordering copy is needed on either side
+  int piece_log = 0;
+  if (pieces > 0) {
+    int lg = 0; while ((1 << lg) < pieces) ++lg;
+    if ((1 << lg) != pieces || pl->npass != 2 || lg > pl->lt[0] || pl->lt[0] > 8 || psi_in)
+      return fail(NTTX_ERANGE, "pieces layout needs a two-pass length (2^15 .. 2^17) and a power-of-two number of pieces up to 2^%d", pl->lt[0]);
+    piece_log = pl->lt[0] - lg;
+  }
   if (pl->npass == 1) {
     RowArgs R{}; R.in0 = a; R.in1 = b; R.out = c; R.tw_fwd = pl->tw_fwd[0]; R.tw_inv = pl->tw_inv[0];
     R.ctx = pl->ctx; R.scale = pl->scale_single; R.canon_out = 1; R.nrows = batch;
@@ -462,17 +472,21 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     C.nblocks = ((long long)batch << pl->logL) >> logN;
     C.nvalid = (lv == 0 && nvalid > 0 && 2 * nvalid <= len) ? nvalid : 0;
     if (lv == 0 && psi_in) { C.psi = psi_in; C.nvalid = 0; }
+    if (lv == 0 && pieces > 0) {
+      C.piece_log = piece_log; C.block_stride = len / pieces; C.piece_stride = (long long)batch * C.block_stride; C.nvalid = 0;
+    }
     if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, st)) return rc;
     logN = C.logS;
   }
   {                                              // rows: forward a, forward b, pointwise, inverse
-    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
+    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = pieces > 0 ? wa : c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
     R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
     if (int rc = launch_row(cx, ROW_MUL, pl->hclass, pl->lt[ncol], R, st)) return rc;
   }
   for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
     int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
-    ColArgs C{}; C.in[0] = c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
+    ColArgs C{}; C.in[0] = pieces > 0 ? wa : c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
+    if (lv == 0 && pieces > 0) { C.piece_log = piece_log; C.block_stride = len / pieces; C.piece_stride = (long long)batch * C.block_stride; }
     C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
     if (lv == 0) { C.fsa = pl->fsa_inv; C.logC2 = pl->logC2; }
     C.nblocks = ((long long)batch << pl->logL) >> logNl;
@@ -963,6 +977,17 @@ int nttx_dev_cyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, in
   Plan *pl;
   if (int rc = get_plan(cx, p, k, false, &pl)) return rc;
   return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, batch, (hipStream_t)stream);
+}
+
+int nttx_dev_cyclic_multiply_pieces_u32(const void *d_a, const void *d_b, void *d_c, int len, int pieces, int rows, uint32_t p,
+                                        void *stream) {
+  NTTX_ENTER_ON(stream);
+  if (!d_a || !d_b || !d_c || rows < 1 || pieces < 1 || len < 2 || (len & (len - 1))) return fail(NTTX_EINVAL, "bad arguments");
+  int k = 0; while ((1ll << k) < len) ++k;
+  Plan *pl;
+  if (int rc = get_plan(cx, p, k, false, &pl)) return rc;
+  return dev_cyclic_multiply(cx, pl, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_c, rows, (hipStream_t)stream, 0,
+                             nullptr, nullptr, nullptr, pieces);
 }
 
 int nttx_dev_negacyclic_multiply_u32(const void *d_a, const void *d_b, void *d_c, int len, uint32_t p, int batch, void *stream) {

@@ -28,7 +28,7 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   // thread and round, until about 256 workgroups exist (one 2^18-point product: 7.8 -> about 2.5 us per pass).
   // NTTX_COL_NARROW=0 keeps full-line tiles (A/B measurements), 2 or 3 forces a width.
   int lc = wide ? 5 : 4;
-  if (wide && logT == 9 && !FS2 && !A.psi) {
+  if (wide && logT == 9 && !FS2 && !A.psi && !A.piece_stride) {
     static const int narrow = env_int("NTTX_COL_NARROW", -1);
     long long w = (A.nblocks << (A.logS - 5)) * nvec;
     if (narrow == 2 || narrow == 3) lc = narrow;
@@ -67,6 +67,21 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
     }
     if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
     return 0;
+  }
+  if (A.piece_stride) {   // rows in the pieces layout of an all-to-all (full-line tiles of 2^6 .. 2^8-point passes)
+    if constexpr (!FS2 && !ZHI) {
+#define NTTX_COLP_CASE(K) \
+      hipLaunchKernelGGL((col_kernel<K, INV, H, 5, 256, false, false, false, (INV ? 2 : 1)>), dim3(grid, 1, nvec), dim3(256), 0, st, A); break;
+      switch ((wide && !A.psi) ? logT : 0) {
+        case 6: NTTX_COLP_CASE(6)  case 7: NTTX_COLP_CASE(7)  case 8: NTTX_COLP_CASE(8)
+        default: return colfail(NTTX_ERANGE, "column pass of this size has no pieces-layout variant");
+      }
+#undef NTTX_COLP_CASE
+      if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
+      return 0;
+    } else {
+      return colfail(NTTX_ERANGE, "pieces layout needs a plain column pass");
+    }
   }
   if (lc < 4) {
     if (lc == 3) { hipLaunchKernelGGL((col_kernel<9, INV, H, 3, 512, ZHI, false>), dim3(grid, 1, nvec), dim3(512), 0, st, A); }

@@ -950,6 +950,10 @@ struct ColArgs {
   long long nblocks;      // batch * L / N
   long long nvalid;       // ZHI kernels: words of each block that hold data; the rest reads as zero
   const uint32_t *psi;    // TWIST kernels (outermost pass of a negacyclic product): psi^i forward, psi^-i inverse, N words
+  // PIECE kernels: every block (a vector of N words) is stored as pieces of 2^piece_log matrix rows; piece q of block
+  // r starts at q * piece_stride + r * block_stride (the layout an all-to-all between processes leaves: [source][row][part])
+  int piece_log;
+  long long piece_stride, block_stride;
 };
 
 // Each thread moves PER = T*COLS/(4*NTHR) 16-byte pieces of a tile; LPR = COLS/4 lanes cover one
@@ -962,9 +966,12 @@ struct ColArgs {
 // outer pass of three-pass lengths, where that table would double the pass's HBM traffic.
 // TWIST: the pass is the outermost one of a negacyclic product: forward inputs are multiplied by psi^i as
 // they are read, inverse outputs by psi^-i before the canonical store.
-template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false, bool TWIST = false>
+// PIECE: 1 = the input (forward pass), 2 = the output (inverse pass) is in the pieces layout of ColArgs, so that rows
+// handed over by an all-to-all are transformed where they arrive and results leave in the layout the way back sends.
+template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false, bool TWIST = false, int PIECE = 0>
 __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColArgs A) {
   static_assert(!TWIST || (!ZHI && !FS2), "twisted passes read whole vectors and use the plain four-step table");
+  static_assert(PIECE == 0 || (!ZHI && !FS2 && !TWIST && PIECE == (INV ? 2 : 1)), "pieces layout: plain passes, input forward / output inverse");
   using L = ColLayout<LOGT, LOGC, NTHR>;
   constexpr int T = L::T, COLS = L::COLS;
   constexpr int LPR = COLS / 4, LOG_LPR = LOGC - 2;
@@ -994,6 +1001,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     return (blk << (logS + LOGT)) + (ct << LOGC);
   };
   auto fs_base = [&](long long t) -> long long { return (t & ((1ll << log_tpb) - 1)) << LOGC; };
+  // the same tile in the pieces layout: block r at r * block_stride, matrix row j in piece j >> piece_log
+  auto piece_base = [&](long long t) -> long long {
+    return (t >> log_tpb) * A.block_stride + ((t & ((1ll << log_tpb) - 1)) << LOGC);
+  };
+  auto piece_row = [&](int j) -> long long {
+    return (long long)(j >> A.piece_log) * A.piece_stride + ((long long)(j & ((1 << A.piece_log) - 1)) << logS);
+  };
   auto fs_load = [&](long long fbase, int j) -> uint4 {
     return *reinterpret_cast<const uint4 *>(A.fs + fbase + ((long long)j << logS) + c4);
   };
@@ -1020,7 +1034,9 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
   // one 16-byte piece of the tile at row j; ZHI masks words at or beyond nvalid of the block
   const bool ragged = ZHI && A.nvalid != ((long long)(T / 2) << logS);
   auto load_piece = [&](long long base, long long t_, int j) -> uint4 {
-    if constexpr (!ZHI) {
+    if constexpr (PIECE == 1) {
+      return *reinterpret_cast<const uint4 *>(in + piece_base(t_) + piece_row(j) + c4);
+    } else if constexpr (!ZHI) {
       return *reinterpret_cast<const uint4 *>(in + base + ((long long)j << logS) + c4);
     } else {
       // every loaded piece lies in a row below T/2; when exactly the lower half holds data no word needs masking
@@ -1111,7 +1127,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
         constexpr int KS = INV ? Arith<H>::KI : Arith<H>::KM;
         x.x = M.canon(V<KS>{x.x}); x.y = M.canon(V<KS>{x.y}); x.z = M.canon(V<KS>{x.z}); x.w = M.canon(V<KS>{x.w});
       }
-      *reinterpret_cast<uint4 *>(out + gbase + ((long long)j << logS) + c4) = x;
+      if constexpr (PIECE == 2) *reinterpret_cast<uint4 *>(out + piece_base(t) + piece_row(j) + c4) = x;
+      else *reinterpret_cast<uint4 *>(out + gbase + ((long long)j << logS) + c4) = x;
     }
   }
 }

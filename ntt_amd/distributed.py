@@ -257,6 +257,22 @@ class HipEngine:
         return c
 
 
+    def cyclic_multiply_pieces(self, a, b, p):
+        """Row-wise cyclic products of two [pieces][rows][len / pieces] int32 tensors (row r = the concatenation of
+        its pieces, as an all-to-all delivers it); the result comes in the same layout.  None when the length has no
+        pieces-layout kernels (the caller then reorders and uses cyclic_multiply)."""
+        t = self._t
+        self._chk(a, t.int32)
+        self._chk(b, t.int32)
+        pieces, rows, part = a.shape
+        length = pieces * part
+        if not (1 << 15 <= length <= 1 << 17) or pieces > length // 512:
+            return None
+        c = t.empty_like(a)
+        self._api.dev_cyclic_multiply_pieces_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), length, pieces, rows, p, self._stream())
+        return c
+
+
 # --------------------------------------------------------------------------------------------
 # 4-prime CRT products, primes dealt to ranks
 # --------------------------------------------------------------------------------------------
@@ -348,9 +364,10 @@ class FourStepSharded:
         so its [dest][rows][cols] view is the send buffer as it stands: no packing copy."""
         return self.comm.all_to_all_start(x.view(self.comm.world, self.rows, self.cols))
 
-    def _rows_of(self, pending):
-        recv = pending.wait()                                                    # [source][rows][cols]
-        return recv.permute(1, 0, 2).reshape(self.rows, self.S)                  # (one copy: rows become contiguous)
+    @staticmethod
+    def _rows_of(recv):
+        g, rows, cols = recv.shape                                               # [source][rows][cols]
+        return recv.permute(1, 0, 2).reshape(rows, g * cols)                     # (one copy: rows become contiguous)
 
     def _to_slab(self, y):
         g = self.comm.world
@@ -374,7 +391,15 @@ class FourStepSharded:
             pa = self._send_rows(xa)
             e.colpass(xb, L, t, self.col0, p, False, zero_hi)
             pb = self._send_rows(xb)
-            ya, yb = self._rows_of(pa), self._rows_of(pb)
+            ra, rb = pa.wait(), pb.wait()                                        # [source][rows][cols] each
+            # the rows are multiplied where the exchange left them and the products come out in the layout the way
+            # back sends ([dest][rows][cols]): no reordering copy on either side
+            zc = e.cyclic_multiply_pieces(ra, rb, p)
+            if zc is not None:
+                xc = self.comm.all_to_all(zc).view(self.T, self.cols)
+                e.colpass(xc, L, t, self.col0, p, True)
+                return xc
+            ya, yb = self._rows_of(ra), self._rows_of(rb)
         yc = e.cyclic_multiply(ya.contiguous(), yb.contiguous(), p)
         xc = self._to_slab(yc).contiguous()
         e.colpass(xc, L, t, self.col0, p, True)

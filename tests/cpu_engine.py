@@ -57,6 +57,16 @@ class OracleEngine:
         out = self.O.crt_combine(flat, len(flat[0]), p)
         return torch.from_numpy(out.view(np.int64).reshape(tuple(shape)))
 
+    def cyclic_multiply_pieces(self, a, b, p):
+        """[pieces][rows][part] layout in and out: row r is the concatenation of its pieces."""
+        pieces, rows, part = a.shape
+        if pieces * part < 64:          # (a length without pieces-layout kernels: the caller must take the other path)
+            return None
+        ya = a.permute(1, 0, 2).reshape(rows, pieces * part).contiguous()
+        yb = b.permute(1, 0, 2).reshape(rows, pieces * part).contiguous()
+        yc = self.cyclic_multiply(ya, yb, p)
+        return yc.view(rows, pieces, part).permute(1, 0, 2).contiguous()
+
     def colpass(self, x, log_len, log_t, col0, p, inverse, zero_hi=False):
         X = _u32(x)                      # view: written back in place
         T, cols = X.shape

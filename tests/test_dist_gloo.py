@@ -163,7 +163,8 @@ def test_exchange_steps_in_process_ranks(oracle):
     with pytest.raises(NttxError) as err:
         ThreadComm.run(1, lambda comm: _run_crt(comm, oracle, a % np.uint64(big), b % np.uint64(big), n, big, True))
     assert err.value.code == -2
-    for p, log_len, log_t, world, linear in ((998244353, 12, 6, 4, False), (1224736769, 13, 7, 2, True), (469762049, 12, 6, 1, True)):
+    for p, log_len, log_t, world, linear in ((998244353, 12, 6, 4, False), (1224736769, 13, 7, 2, True), (469762049, 12, 6, 1, True),
+                                             (469762049, 11, 6, 2, False)):     # the last one: rows too short for the pieces-layout product
         fa, fb, fwant = _fourstep_case(oracle, log_len, p, linear)
         outs = ThreadComm.run(world, lambda comm: _run_fourstep(comm, oracle, fa, fb, log_len, log_t, p, linear))
         full = np.zeros(1 << log_len, dtype=np.uint32)

@@ -163,3 +163,27 @@ def test_fourstep_sharded_large_vs_single_gpu(nttx, oracle, log_len, world):
         lo, hi = max(0, i - (L // 2 - 1)), min(i, L // 2 - 1)
         terms = ah[lo: hi + 1] * bh[i - hi: i - lo + 1][::-1] % np.uint64(p)     # each product < 2^58
         assert int(terms.sum(dtype=np.uint64)) % p == int(fh[i])                # at most 2^21 terms < 2^29
+
+
+@pytest.mark.parametrize("p,log_len,pieces,rows", [(469762049, 15, 2, 3), (469762049, 15, 64, 2), (998244353, 16, 8, 3),
+                                                   (1224736769, 17, 4, 2), (469762049, 17, 256, 1), (1004535809, 15, 1, 2)])
+def test_cyclic_multiply_in_pieces_layout(nttx, oracle, p, log_len, pieces, rows):
+    """nttx_dev_cyclic_multiply_pieces_u32: rows held as [pieces][rows][len / pieces] (what an all-to-all between
+    processes leaves), products returned in the same layout; against the oracle's ntt_compute on the assembled rows."""
+    import torch
+    L = 1 << log_len
+    part = L // pieces
+    a = np.stack([oracle.fill_random(L, 700 + r, p) for r in range(rows)]).astype(np.uint32)
+    b = np.stack([oracle.fill_random(L, 800 + r, p) for r in range(rows)]).astype(np.uint32)
+    to_pieces = lambda x: np.ascontiguousarray(x.reshape(rows, pieces, part).transpose(1, 0, 2))
+    da = torch.from_numpy(to_pieces(a).view(np.int32)).cuda()
+    db = torch.from_numpy(to_pieces(b).view(np.int32)).cuda()
+    dc = torch.full_like(da, 3)
+    nttx.dev_cyclic_multiply_pieces_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), L, pieces, rows, p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy().view(np.uint32).transpose(1, 0, 2).reshape(rows, L)
+    for r in range(rows):
+        assert np.array_equal(got[r], oracle.ntt_compute(a[r], b[r], p)), (p, log_len, pieces, r)
+    assert np.array_equal(da.cpu().numpy().view(np.uint32), to_pieces(a))          # inputs untouched
+    with pytest.raises(nttx.NttxError):                                            # single-pass length: no such variant
+        nttx.dev_cyclic_multiply_pieces_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), 1 << 12, 2, 1, p, 0)

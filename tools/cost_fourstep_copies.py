@@ -1,6 +1,7 @@
 """What one rank of the column-split product (ntt_amd.distributed.FourStepSharded) spends outside the exchange itself,
 measured on ONE GPU with the shapes a rank would hold at G ranks: the column passes, the row products, and the
-layout copies around the two all-to-alls (stack / permute / contiguous).  The all-to-all is replaced by an identity
+layout copies that a reordering implementation needs around the all-to-alls (stack / permute / contiguous), against
+the row products computed directly in the exchanged layout (nttx_dev_cyclic_multiply_pieces_u32: no copies).  The all-to-all is replaced by an identity
 (timing only, results are meaningless).  usage: cost_fourstep_copies.py [log2_len] [G]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -64,6 +65,10 @@ def pack2():
 out["pack_back_us"] = timeit(pack2)
 xc = z.view(fs.T, fs.cols)
 out["colpass_inv_us"] = timeit(lambda: e.colpass(xc, logL, fs.log_t, 0, P, True))
+ra = xa.view(g, fs.rows, fs.cols).clone()
+rb = xb.view(g, fs.rows, fs.cols).clone()
+if e.cyclic_multiply_pieces(ra, rb, P) is not None:
+    out["row_products_in_pieces_layout_us"] = timeit(lambda: e.cyclic_multiply_pieces(ra, rb, P))
 out["copies_us"] = out["pack_for_exchange_us"] + out["unpack_to_rows_us"] + out["pack_back_us"]
 out["kernels_us"] = out["colpass_fwd_a_and_b_us"] + out["row_products_us"] + out["colpass_inv_us"]
 out["exchange_bytes_per_rank"] = int(3 * fs.T * fs.cols * 4 * (G - 1) / G)
