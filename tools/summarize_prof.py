@@ -42,7 +42,7 @@ for r in csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel
 fetch, write, sq, sq2 = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq"), pmc("pmc_sq2")
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 kind = {"col_kernel<9, false": "col_fwd", "row_mul9_kernel": "row_mul", "col_kernel<9, true": "col_inv"}
-traffic, valu_insts = {}, {}
+traffic, valu_insts, clocks = {}, {}, {}
 lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 200 --warmup 50 --no-cpu` (batch 256, L = 2^18, p = 469762049)", "",
          "Kernel trace (`rocprofv3 --kernel-trace --stats`):", "",
          "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
@@ -59,6 +59,7 @@ for n, c, a, *_ in stats:
         if n.startswith(k):
             traffic[v] = hbm
             valu_insts[v] = mean(s["SQ_INSTS_VALU"])
+            clocks[v] = mean(s2["GRBM_GUI_ACTIVE"]) / 8 / (a * 1e-9) / 1e9      # cycles over the kernel's average duration, GHz
     lines.append(f"| `{n}` | {f:.0f} | {w:.0f} | {hbm/1e6:.1f} MB | {mean(s['SQ_INSTS_VALU'])/1e6:.2f} M | {mean(s['SQ_INSTS_LDS'])/1e6:.2f} M | "
                  f"{mean(s['SQ_LDS_BANK_CONFLICT'])/1e6:.2f} M / {mean(s['SQ_LDS_IDX_ACTIVE'])/1e6:.2f} M | {mean(s['SQ_WAVE_CYCLES'])/1e6:.1f} M | "
                  f"{mean(s2['SQ_WAIT_ANY'])/1e6:.1f} M | {mean(s2['SQ_WAIT_INST_ANY'])/1e6:.1f} M | {mean(s2['GRBM_GUI_ACTIVE'])/8/1e3:.1f} k cycles |")
@@ -76,6 +77,7 @@ from bench import kernel_source_tag  # noqa: E402
 meta = {"kernel_source_tag": kernel_source_tag(), "measured_by": f"tools/prof.sh {tag} (bench.py --steps 200 --warmup 50, batch 256)"}
 json.dump(dict(meta, what="HBM bytes per launch: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes", kernels=traffic),
           open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
-json.dump(dict(meta, what="SQ_INSTS_VALU per launch (wave-level vector instructions)", kernels=valu_insts),
+json.dump(dict(meta, what="SQ_INSTS_VALU per launch (wave-level vector instructions); clock_GHz = GRBM_GUI_ACTIVE / 8 / kernel duration "
+                      "in the counter and trace passes", kernels=valu_insts, clock_GHz=clocks),
           open(os.path.join("profiles", "valu.json"), "w"), indent=1)
 print("\n".join(lines))
