@@ -30,7 +30,7 @@ prof = {k: round(v[0] / K, 4) for k, v in ntt_amd.profile_read().items() if v[1]
 L = 2 * n
 print(json.dumps({"workload": "CRT route, n=2^17, p=%d" % P, "batch": B, "poly_mults_per_s": B * K / dt,
                   "us_per_mult": dt / (B * K) * 1e6, "ns_per_butterfly": dt / (B * K) / (4 * 3 * (L // 2) * 18) * 1e9,
-                  "kernels_ms_per_step": prof, "model_bytes_280L": 280 * L, "model_GBs": 280 * L * B * K / dt / 1e9}))
+                  "kernels_ms_per_step": prof, "model_bytes_280L": 280 * L, "model_280L_bytes_x_rate_GBs_NOT_traffic": 280 * L * B * K / dt / 1e9}))
 if ntt_amd.path_for(P, n) != ntt_amd.PATH_DIRECT64:
     ntt_amd.shutdown()
     sys.exit(0)

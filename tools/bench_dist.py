@@ -117,7 +117,7 @@ def main():
         out["kernels_ms_per_step"] = {k: round(v[0] / 10, 4) for k, v in ntt_amd.profile_read().items() if v[1] > 0}
         out.update(batch=B, p=P32, log2_len=logL, poly_mults_per_s=B * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
                    us_per_mult_per_gpu=dt / args.steps / nb * 1e6, passes=ntt_amd.plan_info(L),
-                   model_GBs_per_gpu=52 * L * nb * args.steps / dt / 1e9)
+                   model_52L_bytes_x_rate_GBs_NOT_traffic=52 * L * nb * args.steps / dt / 1e9)
     elif args.workload == "nega":
         logN = args.log_len or 12
         N, B = 1 << logN, args.batch or 4096
@@ -164,7 +164,7 @@ def main():
                         args.steps, args.warmup, torch, dist, dev)
             same = bool(torch.equal(c.view(fs.T, fs.S), fs.multiply(xa.clone(), xb.clone(), zero_hi=True)))
             out.update(single_plan_ms_per_product=dt1 / args.steps * 1e3, single_plan_passes=ntt_amd.plan_info(L),
-                       single_plan_model_GBs=52 * L * args.steps / dt1 / 1e9, matches_single_plan=same)
+                       single_plan_model_52L_bytes_x_rate_GBs_NOT_traffic=52 * L * args.steps / dt1 / 1e9, matches_single_plan=same)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
