@@ -77,3 +77,29 @@ def test_static_scratch_entry_point_limits(nttx, oracle):
     nttx.dev_poly_multiply_u32_static(da.data_ptr(), db.data_ptr(), got.data_ptr(), 131072, P, 16, st)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_static_scratch_entry_point_under_graph_capture(nttx, oracle):
+    """The callers this entry point is for: a HIP graph captures it (nothing in it allocates or synchronises) and
+    replays give the eager result."""
+    import torch
+    n, length, batch = 131072, 1 << 18, 2
+    a, b, da, db = _inputs(torch, oracle, batch, n, length, 51)
+    eager, replayed = torch.empty_like(da), torch.zeros_like(da)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        # set-up on the stream that will be captured: builds the tables (allocating entry point) and makes that stream
+        # the one the library saw last, so that the captured call records no cross-stream wait
+        nttx.dev_poly_multiply_u32(da.data_ptr(), db.data_ptr(), eager.data_ptr(), n, P, batch, side.cuda_stream)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            nttx.dev_poly_multiply_u32_static(da.data_ptr(), db.data_ptr(), replayed.data_ptr(), n, P, batch,
+                                              torch.cuda.current_stream().cuda_stream)
+    assert int(replayed.abs().max()) == 0          # capture records, it does not run
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(replayed, eager)
+    want = oracle.poly_multiply_crt(a[1, :n].astype(np.uint64), b[1, :n].astype(np.uint64), P)
+    assert np.array_equal(replayed[1].cpu().numpy().view(np.uint32)[: 2 * n - 1].astype(np.uint64), want)
