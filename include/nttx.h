@@ -182,6 +182,13 @@ int nttx_crt_primes_for(uint64_t p, int n, uint32_t primes[4]);
 int nttx_dev_crt_residues_u64(const void *d_a, const void *d_b, void *d_res, int n, int prime_mask, int batch,
                               void *stream);
 
+/* The same with the residues laid out for the exchange between the processes that share the primes: d_res is
+ * [slice][selected primes][batch][len / slices], slice q holding indices q*len/slices .. (q+1)*len/slices - 1 of every
+ * vector, i.e. the send buffer of an all-to-all over `slices` processes as it stands (no reordering copy; the last
+ * inverse pass writes it).  slices a power of two; lengths 2^15 .. 2^20 (two-pass plans); slices = 1 is the call above. */
+int nttx_dev_crt_residues_sliced_u64(const void *d_a, const void *d_b, void *d_res, int n, int prime_mask, int batch,
+                                     int slices, void *stream);
+
 /* CRT recombination of a slice (main.cc:323-337, crt_thread_func main_pthread.cc:293-310 works on
  * [start,end) the same way): d_out[i] = x_i mod p for i < count, where x_i < M has the residues
  * d_rk[i] modulo modulus k.  All device memory, u32 in, u64 out. */

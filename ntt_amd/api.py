@@ -44,6 +44,7 @@ _SIGS = [
     ("nttx_crt_prime", C.c_int, [C.c_int, _u32p]),
     ("nttx_crt_primes_for", C.c_int, [C.c_uint64, C.c_int, _u32p]),
     ("nttx_dev_crt_residues_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("nttx_dev_crt_residues_sliced_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_dev_crt_recombine_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint64, C.c_void_p]),
     ("nttx_dev_colpass_u32", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     ("nttx_dev_direct_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
@@ -286,6 +287,11 @@ def crt_primes_for(p: int, n: int):
 def dev_crt_residues_u64(d_a: int, d_b: int, d_res: int, n: int, prime_mask: int, batch: int, stream: int = 0):
     """Residues of the products modulo the CRT primes in prime_mask -> [primes][batch][len] u32."""
     _check(lib().nttx_dev_crt_residues_u64(d_a, d_b, d_res, n, prime_mask, batch, stream))
+
+
+def dev_crt_residues_sliced_u64(d_a: int, d_b: int, d_res: int, n: int, prime_mask: int, batch: int, slices: int, stream: int = 0):
+    """Residues laid out [slice][primes][batch][len / slices]: the send buffer of the exchange between `slices` processes."""
+    _check(lib().nttx_dev_crt_residues_sliced_u64(d_a, d_b, d_res, n, prime_mask, batch, slices, stream))
 
 
 def dev_crt_recombine_u64(d_r, d_out: int, count: int, p: int, stream: int = 0):

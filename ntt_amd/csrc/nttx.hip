@@ -434,17 +434,26 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 // context's grow-only workspace (the caller has checked the size), and nothing is allocated
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
                                hipStream_t st, long long nvalid = 0, const uint32_t *psi_in = nullptr,
-                               const uint32_t *psi_out = nullptr, uint32_t *ws = nullptr, int pieces = 0) {
+                               const uint32_t *psi_out = nullptr, uint32_t *ws = nullptr, int pieces = 0,
+                               int out_slices = 0, long long out_slice_stride = 0) {
   const long long len = 1ll << pl->logL;
   if (psi_in && pl->npass > 2) return fail(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
   // pieces > 0: a, b and c are [pieces][batch][len / pieces] arrays (vector r = the concatenation of its pieces), the
   // layout in which an all-to-all between processes delivers rows and takes them back: the first forward pass reads
   // it and the last inverse pass writes it, so no reordering copy is needed on either side
+  // out_slices > 0 (CRT residues for several processes): only c is in pieces form, slice q of every vector going to
+  // c + q * out_slice_stride (slice q = what process q recombines); a and b are ordinary [batch][len] arrays
   int piece_log = 0;
   if (pieces > 0) {
     int lg = 0; while ((1 << lg) < pieces) ++lg;
     if ((1 << lg) != pieces || pl->npass != 2 || lg > pl->lt[0] || pl->lt[0] > 8 || psi_in)
       return fail(NTTX_ERANGE, "pieces layout needs a two-pass length (2^15 .. 2^17) and a power-of-two number of pieces up to 2^%d", pl->lt[0]);
+    piece_log = pl->lt[0] - lg;
+    out_slices = pieces; out_slice_stride = (long long)batch * (len / pieces);
+  } else if (out_slices > 0) {
+    int lg = 0; while ((1 << lg) < out_slices) ++lg;
+    if ((1 << lg) != out_slices || pl->npass != 2 || lg > pl->lt[0] || psi_in)
+      return fail(NTTX_ERANGE, "sliced output needs a two-pass length and a power-of-two number of slices up to 2^%d", pl->lt[0]);
     piece_log = pl->lt[0] - lg;
   }
   if (pl->npass == 1) {
@@ -479,14 +488,14 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     logN = C.logS;
   }
   {                                              // rows: forward a, forward b, pointwise, inverse
-    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = pieces > 0 ? wa : c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
+    RowArgs R{}; R.in0 = wa; R.in1 = wb; R.out = out_slices > 0 ? wa : c; R.tw_fwd = pl->tw_fwd[ncol]; R.tw_inv = pl->tw_inv[ncol];
     R.ctx = pl->ctx; R.scale = 0; R.canon_out = 0; R.nrows = ((long long)batch << pl->logL) >> pl->lt[ncol];
     if (int rc = launch_row(cx, ROW_MUL, pl->hclass, pl->lt[ncol], R, st)) return rc;
   }
   for (int lv = ncol - 1; lv >= 0; --lv) {       // inverse column passes, innermost level first
     int logNl = pl->logL; for (int q = 0; q < lv; ++q) logNl -= pl->lt[q];
-    ColArgs C{}; C.in[0] = pieces > 0 ? wa : c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
-    if (lv == 0 && pieces > 0) { C.piece_log = piece_log; C.block_stride = len / pieces; C.piece_stride = (long long)batch * C.block_stride; }
+    ColArgs C{}; C.in[0] = out_slices > 0 ? wa : c; C.in[1] = nullptr; C.out[0] = c; C.out[1] = nullptr;
+    if (lv == 0 && out_slices > 0) { C.piece_log = piece_log; C.block_stride = len / out_slices; C.piece_stride = out_slice_stride; }
     C.tw = pl->tw_inv[lv]; C.fs = pl->fs_inv[lv]; C.ctx = pl->ctx; C.logS = logNl - pl->lt[lv]; C.canon_out = (lv == 0);
     if (lv == 0) { C.fsa = pl->fsa_inv; C.logC2 = pl->logC2; }
     C.nblocks = ((long long)batch << pl->logL) >> logNl;
@@ -588,7 +597,7 @@ static bool crt_side_by_side(size_t words, int ns, int npass) {
   return mode == 1 || (words >= ((size_t)6 << 18) && words <= ((size_t)512 << 18));
 }
 static int crt_products(Context *cx, Plan *const pl[4], int ns, const uint32_t *pa, const uint32_t *pb, uint32_t *const out[4],
-                        int batch, int n, hipStream_t st) {
+                        int batch, int n, hipStream_t st, int out_slices = 0, long long out_slice_stride = 0) {
   const long long len = 1ll << pl[0]->logL;
   const size_t words = (size_t)batch * len;
   const bool par = crt_side_by_side(words, ns, pl[0]->npass);
@@ -600,7 +609,8 @@ static int crt_products(Context *cx, Plan *const pl[4], int ns, const uint32_t *
   for (int k = 0; k < ns; ++k) {
     hipStream_t sk = (par && k > 0) ? cx->side[k - 1] : st;
     uint32_t *ws = (par && k > 0) ? cx->wsx.as<uint32_t>() + (size_t)(k - 1) * 2 * words : nullptr;
-    if (int rc = dev_cyclic_multiply(cx, pl[k], pa + (size_t)k * words, pb + (size_t)k * words, out[k], batch, sk, n, nullptr, nullptr, ws)) return rc;
+    if (int rc = dev_cyclic_multiply(cx, pl[k], pa + (size_t)k * words, pb + (size_t)k * words, out[k], batch, sk, n, nullptr, nullptr, ws,
+                                     0, out_slices, out_slice_stride)) return rc;
   }
   if (par) {
     for (int k = 1; k < ns; ++k) {
@@ -663,8 +673,10 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
 // residues of the products modulo the CRT primes selected by prime_mask (bit k = kCrtPrimes[k]):
 // d_res gets [selected primes, ascending k][batch][len] canonical u32 (the per-prime half of
 // main.cc:292-311, for processes that each own some of the primes)
+// slices > 1: d_res is [slice][selected primes][batch][len / slices] instead (slice q = indices q*len/slices ..), the send
+// buffer of the all-to-all that hands every process its slice of all residues
 static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_b, uint32_t *d_res, int n, int prime_mask,
-                            int batch, hipStream_t st) {
+                            int batch, hipStream_t st, int slices = 1) {
   const int logL = log2_ceil_len(n);
   if (logL > 21) return fail(NTTX_ERANGE, "length 2^%d exceeds the CRT prime set (2^21)", logL);
   if (prime_mask <= 0 || prime_mask > 15) return fail(NTTX_EINVAL, "prime mask must select 1..4 of the CRT primes");
@@ -690,6 +702,11 @@ static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_
   cx->prof.end(st);
   HIPCHK(hipGetLastError());
   uint32_t *outs[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (slices > 1) {
+    const long long sl = len / slices;
+    for (int i = 0; i < ns; ++i) outs[i] = d_res + (size_t)i * batch * sl;
+    return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st, slices, (long long)ns * batch * sl);
+  }
   for (int i = 0; i < ns; ++i) outs[i] = d_res + (size_t)i * batch * len;
   return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st);
 }
@@ -1037,6 +1054,13 @@ int nttx_dev_crt_residues_u64(const void *d_a, const void *d_b, void *d_res, int
   NTTX_ENTER_ON(stream);
   if (!d_a || !d_b || !d_res || batch < 1 || n < 1) return fail(NTTX_EINVAL, "bad arguments");
   return dev_crt_residues(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint32_t *)d_res, n, prime_mask, batch, (hipStream_t)stream);
+}
+
+int nttx_dev_crt_residues_sliced_u64(const void *d_a, const void *d_b, void *d_res, int n, int prime_mask, int batch, int slices,
+                                     void *stream) {
+  NTTX_ENTER_ON(stream);
+  if (!d_a || !d_b || !d_res || batch < 1 || n < 1 || slices < 1) return fail(NTTX_EINVAL, "bad arguments");
+  return dev_crt_residues(cx, (const uint64_t *)d_a, (const uint64_t *)d_b, (uint32_t *)d_res, n, prime_mask, batch, (hipStream_t)stream, slices);
 }
 
 int nttx_dev_crt_recombine_u64(const void *d_r0, const void *d_r1, const void *d_r2, const void *d_r3, void *d_out,

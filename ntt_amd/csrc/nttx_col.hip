@@ -74,6 +74,9 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
       hipLaunchKernelGGL((col_kernel<K, INV, H, 5, 256, false, false, false, (INV ? 2 : 1)>), dim3(grid, 1, nvec), dim3(256), 0, st, A); break;
       switch ((wide && !A.psi) ? logT : 0) {
         case 6: NTTX_COLP_CASE(6)  case 7: NTTX_COLP_CASE(7)  case 8: NTTX_COLP_CASE(8)
+        case 9:   // (inverse only: the sliced residues of 2^18-point CRT products)
+          if constexpr (INV) { hipLaunchKernelGGL((col_kernel<9, true, H, 5, 1024, false, false, false, 2>), dim3(grid, 1, nvec), dim3(1024), 0, st, A); break; }
+          return colfail(NTTX_ERANGE, "column pass of this size has no pieces-layout variant");
         default: return colfail(NTTX_ERANGE, "column pass of this size has no pieces-layout variant");
       }
 #undef NTTX_COLP_CASE

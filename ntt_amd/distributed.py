@@ -230,6 +230,22 @@ class HipEngine:
         self._api.dev_crt_residues_u64(a.data_ptr(), b.data_ptr(), res.data_ptr(), n, prime_mask, batch, self._stream())
         return res
 
+    def crt_residues_sliced(self, a, b, n, prime_mask, slices):
+        """The same residues as [slices][primes in mask][batch][len / slices] (slice q = indices q*len/slices ..): the
+        send buffer of the exchange between the processes that share the primes, written in place by the last pass.
+        None when the length has no such kernels (the caller then slices the ordinary layout with a copy)."""
+        t = self._t
+        self._chk(a, t.int64)
+        self._chk(b, t.int64)
+        length = self.product_len(n)
+        if not (1 << 15 <= length <= 1 << 20):
+            return None
+        batch = a.shape[0]
+        nsel = bin(prime_mask).count("1")
+        res = t.empty((slices, nsel, batch, length // slices), dtype=t.int32, device=a.device)
+        self._api.dev_crt_residues_sliced_u64(a.data_ptr(), b.data_ptr(), res.data_ptr(), n, prime_mask, batch, slices, self._stream())
+        return res
+
     def crt_recombine(self, residues, p):
         """residues: four int32 tensors of equal shape -> int64 tensor of that shape."""
         t = self._t
@@ -311,13 +327,19 @@ class CrtSharded:
         # product ("sum % M", main.cc:330) - the same check, and the same NTTX_ERANGE, as the single-GPU entry point
         from . import api
         api.crt_primes_for(p, n)
-        res = self.engine.crt_residues(a, b, n, self.mask)              # [nown][nb][len]
-        nown, nb, length = res.shape
         if gp == 1:
+            res = self.engine.crt_residues(a, b, n, self.mask)          # [nown][nb][len]
             full = self.engine.crt_recombine([res[k] for k in range(CRT_PRIME_COUNT)], p)
             return full[:, : 2 * n - 1] if gather else full
-        sl = length // gp
-        send = res.view(nown, nb, gp, sl).permute(2, 0, 1, 3).contiguous()   # [dest][nown][nb][sl]
+        # [dest][nown][nb][sl]: written in that order by the last inverse pass where the length allows it, otherwise
+        # sliced out of the ordinary layout with one copy
+        send = self.engine.crt_residues_sliced(a, b, n, self.mask, gp)
+        if send is None:
+            res = self.engine.crt_residues(a, b, n, self.mask)          # [nown][nb][len]
+            nown, nb, length = res.shape
+            send = res.view(nown, nb, gp, length // gp).permute(2, 0, 1, 3).contiguous()
+        _, nown, nb, sl = send.shape
+        length = sl * gp
         recv = self.group.all_to_all(send)                                    # [source][nown][nb][sl]
         by_prime = [recv[k % gp, k // gp] for k in range(CRT_PRIME_COUNT)]
         part = self.engine.crt_recombine(by_prime, p)                          # [nb][sl]

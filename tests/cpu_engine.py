@@ -51,6 +51,14 @@ class OracleEngine:
                 res[i, r] = self.O.ntt_compute(pa, pb, m)
         return torch.from_numpy(res.view(np.int32))
 
+    def crt_residues_sliced(self, a, b, n, prime_mask, slices):
+        length = self.product_len(n)
+        if length < 64:                 # (a length without sliced kernels: the caller must take the other path)
+            return None
+        res = self.crt_residues(a, b, n, prime_mask)
+        nsel, batch, _ = res.shape
+        return res.view(nsel, batch, slices, length // slices).permute(2, 0, 1, 3).contiguous()
+
     def crt_recombine(self, residues, p):
         shape = residues[0].shape
         flat = [np.ascontiguousarray(_u32(r.contiguous()).reshape(-1)) for r in residues]

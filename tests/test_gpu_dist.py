@@ -187,3 +187,26 @@ def test_cyclic_multiply_in_pieces_layout(nttx, oracle, p, log_len, pieces, rows
     assert np.array_equal(da.cpu().numpy().view(np.uint32), to_pieces(a))          # inputs untouched
     with pytest.raises(nttx.NttxError):                                            # single-pass length: no such variant
         nttx.dev_cyclic_multiply_pieces_u32(da.data_ptr(), db.data_ptr(), dc.data_ptr(), 1 << 12, 2, 1, p, 0)
+
+
+@pytest.mark.parametrize("n,mask,slices,batch", [(131072, 0b0101, 2, 2), (131072, 0b1000, 4, 3), (20000, 0b1111, 4, 2), (300000, 0b0011, 2, 1)])
+def test_crt_residues_sliced_layout(nttx, oracle, n, mask, slices, batch):
+    """nttx_dev_crt_residues_sliced_u64 writes [slice][prime][batch][len / slices], the send buffer of the exchange
+    between the processes that share the primes: the same words as the ordinary layout, sliced."""
+    from ntt_amd.distributed import HipEngine
+    e = HipEngine()
+    a = np.stack([oracle.fill_random(n, 910 + r, P64) for r in range(batch)])
+    b = np.stack([oracle.fill_random(n, 920 + r, P64) for r in range(batch)])
+    da, db = _dev(a.view(np.int64)), _dev(b.view(np.int64))
+    plain = e.crt_residues(da, db, n, mask)                    # [primes][batch][len], checked against the oracle elsewhere
+    sliced = e.crt_residues_sliced(da, db, n, mask, slices)
+    torch.cuda.synchronize()
+    nsel, _, length = plain.shape
+    want = plain.view(nsel, batch, slices, length // slices).permute(2, 0, 1, 3)
+    assert torch.equal(sliced, want.contiguous())
+    k = [i for i in range(4) if mask >> i & 1][0]
+    m = CRT_PRIMES[k]
+    pa, pb = np.zeros(length, np.uint32), np.zeros(length, np.uint32)
+    pa[:n], pb[:n] = (a[0] % np.uint64(m)).astype(np.uint32), (b[0] % np.uint64(m)).astype(np.uint32)
+    got = sliced[:, 0, 0].reshape(-1).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, oracle.ntt_compute(pa, pb, m))
