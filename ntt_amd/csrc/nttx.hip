@@ -350,10 +350,10 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
     static const int capl = env_int("NTTX_GRID_LROW", 1 << 20);
     const int grid = grid_for(A.nrows, capl);
 #define NTTX_LROW_CASE(K) case K: { \
-      constexpr int NT_ = LongRowLayout<K>::NTHR; \
+      constexpr int NT_ = LongRowLayout<K>::NTHR, NTM_ = LongRowLayout<K, long_row_wide(K)>::NTHR; \
       if (MODE != ROW_MUL) hipLaunchKernelGGL((longrow_kernel<K, (MODE == ROW_MUL ? ROW_FWD : MODE), H>), dim3(grid), dim3(NT_), 0, st, A); \
-      else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 0, TWIST>), dim3(grid), dim3(NT_), 0, st, A); \
-      else hipLaunchKernelGGL((longrow_mul_kernel<K, H, TWIST>), dim3(grid), dim3(NT_), 0, st, A); \
+      else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 0, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
+      else hipLaunchKernelGGL((longrow_mul_kernel<K, H, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
       break; }
     switch (logT) { NTTX_LROW_CASE(10) NTTX_LROW_CASE(11) NTTX_LROW_CASE(12) NTTX_LROW_CASE(13) NTTX_LROW_CASE(14) default: break; }
 #undef NTTX_LROW_CASE

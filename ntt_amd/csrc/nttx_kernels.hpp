@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "nttx_arith.hpp"
 
 namespace nttx {
@@ -36,7 +37,7 @@ constexpr int WG = 256;          // threads per workgroup of the row kernels
 // known to fit below 2^32 for the modulus class: 2 (p < 2^31), 4 (p < 2^30), 9 (p < 2^32/9).
 // ------------------------------------------------------------------------------------
 template <int K>
-struct V { uint32_t v; };
+struct V { uint32_t v; static constexpr int bound = K; };
 template <class A, class B>
 struct Pair { A a; B b; };
 template <class A, class B>
@@ -252,6 +253,56 @@ __device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8],
   x[2] = M.template out<KOUT>(r26.a); x[6] = M.template out<KOUT>(r26.b); x[3] = M.template out<KOUT>(r37.a); x[7] = M.template out<KOUT>(r37.b);
 }
 
+// Radix-16 units: one more stage at distance 8D around two radix-8 units (w[8 + j] = tw[lo + (8 + j) D] are
+// its twiddles, the two halves share w[1 .. 7]).  Used where 16 points of a thread meet anyway: the outermost and the
+// distance-1 round of rows of 2^13 and 2^14 points, which then need four trips through LDS instead of five.
+template <int H, bool UNIT_D1, int KIN, int KOUT>
+__device__ __forceinline__ void r16_dif(uint32_t (&x)[16], const uint32_t (&w)[16], const Arith<H> &M) {
+  using PR = decltype(M.dif(V<KIN>{0u}, V<KIN>{0u}, 0u));
+  constexpr int KLO = decltype(PR::a)::bound, KHI = decltype(PR::b)::bound;
+  uint32_t lo[8], hi[8], w8[8];
+  if constexpr (UNIT_D1) {
+    const auto pr = M.bf1(V<KIN>{x[0]}, V<KIN>{x[8]});
+    static_assert(decltype(pr.a)::bound <= KLO, "sum bound");
+    lo[0] = pr.a.v; hi[0] = M.template reduce<KHI>(pr.b).v;
+  } else {
+    const auto pr = M.dif(V<KIN>{x[0]}, V<KIN>{x[8]}, w[8]);
+    lo[0] = pr.a.v; hi[0] = pr.b.v;
+  }
+#pragma unroll
+  for (int j = 1; j < 8; ++j) {
+    const auto pr = M.dif(V<KIN>{x[j]}, V<KIN>{x[j + 8]}, w[8 + j]);
+    lo[j] = pr.a.v; hi[j] = pr.b.v;
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) w8[m] = w[m];
+  r8_dif<H, UNIT_D1, false, KLO, KOUT>(lo, w8, M);
+  r8_dif<H, UNIT_D1, false, KHI, KOUT>(hi, w8, M);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { x[j] = lo[j]; x[j + 8] = hi[j]; }
+}
+template <int H, bool UNIT_D1, int KIN, int KOUT>
+__device__ __forceinline__ void r16_dit(uint32_t (&x)[16], const uint32_t (&w)[16], const Arith<H> &M) {
+  constexpr int KI = Arith<H>::KI;
+  uint32_t lo[8], hi[8], w8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { lo[j] = x[j]; hi[j] = x[j + 8]; w8[j] = w[j]; }
+  r8_dit<H, UNIT_D1, KIN, KI>(lo, w8, M);
+  r8_dit<H, UNIT_D1, KIN, KI>(hi, w8, M);
+  if constexpr (UNIT_D1) {
+    const auto pr = M.bf1(V<KI>{lo[0]}, V<KI>{hi[0]});
+    x[0] = M.template out<KOUT>(pr.a); x[8] = M.template out<KOUT>(pr.b);
+  } else {
+    const auto pr = M.dit(V<KI>{lo[0]}, V<KI>{hi[0]}, w[8]);
+    x[0] = M.template out<KOUT>(pr.a); x[8] = M.template out<KOUT>(pr.b);
+  }
+#pragma unroll
+  for (int j = 1; j < 8; ++j) {
+    const auto pr = M.dit(V<KI>{lo[j]}, V<KI>{hi[j]}, w[8 + j]);
+    x[j] = M.template out<KOUT>(pr.a); x[j + 8] = M.template out<KOUT>(pr.b);
+  }
+}
+
 template <int H, bool UNIT_D1, bool INV, int KIN, int KOUT>
 __device__ __forceinline__ void r4_unit(uint32_t (&x)[4], const uint32_t (&w)[4], const Arith<H> &M) {
   const V<KIN> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]};
@@ -352,7 +403,10 @@ __device__ __forceinline__ void ntt_round(uint32_t *const (&s)[NV], const uint32
       uint32_t x[NP];
 #pragma unroll
       for (int q = 0; q < NP; ++q) x[q] = (ZHI && q >= NP / 2) ? 0u : s[v][a0 + L::padj(q * D)];
-      if constexpr (R == 3) {
+      if constexpr (R == 4) {
+        static_assert(!ZHI, "no zero-half variant of the radix-16 unit");
+        if constexpr (!INV) r16_dif<H, D == 1, KIN, KOUT>(x, w, M); else r16_dit<H, D == 1, KIN, KOUT>(x, w, M);
+      } else if constexpr (R == 3) {
         if constexpr (!INV) r8_dif<H, D == 1, ZHI, KIN, KOUT>(x, w, M); else r8_dit<H, D == 1, KIN, KOUT>(x, w, M);
       } else if constexpr (R == 2) {
         r4_unit<H, D == 1, INV, KIN, KOUT>(x, w, M);
@@ -739,12 +793,13 @@ __global__ void __launch_bounds__(WG, NTTX_ROW9_WAVES) row_mul9_kernel(RowArgs A
 // rounds at distance <= 64 come from an LDS copy of the first 512 table words, the outer rounds
 // read the table through the caches.
 // ------------------------------------------------------------------------------------
-template <int LOGT_>
+// WIDE: sixteen points per thread (the fused product, whose outermost round is a radix-16 unit per thread)
+template <int LOGT_, bool WIDE = false>
 struct LongRowLayout {
   static constexpr int LOGT = LOGT_;
   static constexpr int T = 1 << LOGT;
   static constexpr int NT = 1;
-  static constexpr int NTHR = (LOGT <= 11) ? (T / 8) : (LOGT <= 13) ? 512 : 1024;
+  static constexpr int NTHR = WIDE ? (T / 16) : (LOGT <= 11) ? (T / 8) : (LOGT <= 13) ? 512 : 1024;
   static constexpr int TP = T + (T >> 6) * 8;
   static constexpr int WORDS = TP;
   __device__ static constexpr int padj(int j) { return j + ((j >> 6) << 3); }
@@ -754,45 +809,46 @@ struct LongRowLayout {
 };
 constexpr int LONG_TWL = 512;   // leading words of each stage table kept in LDS
 
-template <class L, int REM, int H>
+// forward rounds through LDS between the outermost round and the distance-1 round, stages LOGD_HI - 1 down to LOGD_LO:
+// radix-8 units, led by one round of radix-16 units when the number of stages is 1 mod 3
+template <class L, int LOGD_HI, int LOGD_LO, int H>
 __device__ __forceinline__ void long_head(uint32_t *s, const uint32_t *twg, const uint32_t *twl, const Arith<H> &M) {
   constexpr int KF = Arith<H>::KF;
-  if constexpr (REM > 3) {
+  static_assert(LOGD_HI >= LOGD_LO && (LOGD_HI - LOGD_LO) % 3 != 2, "rounds of three or four stages");
+  if constexpr (LOGD_HI > LOGD_LO) {
+    constexpr int R = ((LOGD_HI - LOGD_LO) % 3 == 1) ? 4 : 3;
+    constexpr int LOGD = LOGD_HI - R;
     uint32_t *const v[1] = {s};
-    ntt_round<L, 3, REM - 3, false, H, 1, false, KF, KF, true>(v, (8 << (REM - 3)) <= LONG_TWL ? twl : twg, M);
+    ntt_round<L, R, LOGD, false, H, 1, false, KF, KF, true>(v, ((1 << R) << LOGD) <= LONG_TWL ? twl : twg, M);
     __syncthreads();
-    long_head<L, REM - 3, H>(s, twg, twl, M);
+    long_head<L, LOGD, LOGD_LO, H>(s, twg, twl, M);
   }
 }
-// inverse rounds between the distance-1 round and the outermost one (which stores to global memory)
-template <class L, int REM, int H>
+// the same stages of the inverse, smallest distance first
+template <class L, int LOGD_LO, int LOGD_HI, int H>
 __device__ __forceinline__ void long_tail(uint32_t *s, const uint32_t *twg, const uint32_t *twl, const Arith<H> &M) {
   constexpr int KI = Arith<H>::KI;
-  if constexpr (REM > 3) {
-    long_tail<L, REM - 3, H>(s, twg, twl, M);
-    if constexpr (REM < L::LOGT) {
-      uint32_t *const v[1] = {s};
-      ntt_round<L, 3, REM - 3, true, H, 1, false, KI, KI, true>(v, (8 << (REM - 3)) <= LONG_TWL ? twl : twg, M);
-      __syncthreads();
-    }
+  if constexpr (LOGD_LO < LOGD_HI) {
+    constexpr int R = ((LOGD_HI - LOGD_LO) % 3 == 1) ? 4 : 3;
+    uint32_t *const v[1] = {s};
+    ntt_round<L, R, LOGD_LO, true, H, 1, false, KI, KI, true>(v, ((1 << R) << LOGD_LO) <= LONG_TWL ? twl : twg, M);
+    __syncthreads();
+    long_tail<L, LOGD_LO + R, LOGD_HI, H>(s, twg, twl, M);
   }
 }
 // distance-1 round on registers: r[u*NP + q] = point q of the thread's u-th unit
 template <class L, int RL, bool INV, int H, int KIN, int KOUT, int PT>
-__device__ __forceinline__ void long_edge(uint32_t *s, const uint32_t *tw, const Arith<H> &M, uint32_t (&r)[PT]) {
+__device__ __forceinline__ void long_edge(uint32_t *s, const uint32_t (&w)[1 << RL], const Arith<H> &M, uint32_t (&r)[PT]) {
   constexpr int NP = 1 << RL, NU = PT / NP;
   static_assert((L::T >> RL) == NU * L::NTHR, "PT points per thread");
-  uint32_t w[NP];
-  w[0] = 0;
-#pragma unroll
-  for (int m = 1; m < NP; ++m) w[m] = tw[m];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int a0 = L::padj((threadIdx.x + u * L::NTHR) << RL);
     uint32_t x[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) x[q] = INV ? r[u * NP + q] : s[a0 + q];
-    if constexpr (RL == 3) { if constexpr (!INV) r8_dif<H, true, false, KIN, KOUT>(x, w, M); else r8_dit<H, true, KIN, KOUT>(x, w, M); }
+    if constexpr (RL == 4) { if constexpr (!INV) r16_dif<H, true, KIN, KOUT>(x, w, M); else r16_dit<H, true, KIN, KOUT>(x, w, M); }
+    else if constexpr (RL == 3) { if constexpr (!INV) r8_dif<H, true, false, KIN, KOUT>(x, w, M); else r8_dit<H, true, KIN, KOUT>(x, w, M); }
     else if constexpr (RL == 2) r4_unit<H, true, INV, KIN, KOUT>(x, w, M);
     else r2_unit<H, true, INV, KIN, KOUT>(x, w, M);
 #pragma unroll
@@ -801,79 +857,89 @@ __device__ __forceinline__ void long_edge(uint32_t *s, const uint32_t *tw, const
 }
 
 // TWIST: negacyclic product of whole vectors (single pass, canonical output), psi factors applied in registers.
+// Rounds (stages per round; the first runs on registers straight from global memory, the last on registers too):
+//   2^10: 3 | 3 3 | 1    2^11: 3 | 3 3 | 2    2^12: 3 | 3 3 | 3    2^13: 4 | 3 3 | 3    2^14: 4 | 3 3 | 4
+// From 2^13 points on a thread owns sixteen points and the outermost round is one radix-16 unit per thread (at 2^14 the
+// distance-1 round as well), which keeps those rows at three trips through LDS per transform instead of four.  Shorter
+// rows measured no faster that way (2^10: -2 %, 2^12: +3 %) and lose parallelism when a launch has few rows
+// (2^20 as 512 rows of 2^11: 16.0 against 11.6 us), so they keep eight points per thread.
+constexpr bool long_row_wide(int logt) { return logt >= 13; }
 template <int LOGT, int H, bool TWIST = false>
-__global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(RowArgs A) {
-  using L = LongRowLayout<LOGT>;
+__global__ void __launch_bounds__((LongRowLayout<LOGT, long_row_wide(LOGT)>::NTHR)) longrow_mul_kernel(RowArgs A) {
+  using L = LongRowLayout<LOGT, long_row_wide(LOGT)>;
   constexpr int T = L::T, NTHR = L::NTHR;
-  constexpr int RL = (LOGT - 1) % 3 + 1;          // stages of the distance-1 round
-  constexpr int D1 = T / 8, LOGD1 = LOGT - 3;     // outermost round
-  constexpr int NU = D1 / NTHR;                   // outermost-round units per thread
+  constexpr int RO = long_row_wide(LOGT) ? 4 : 3;                                          // stages of the outermost round
+  constexpr int RL = !long_row_wide(LOGT) ? (LOGT - 1) % 3 + 1 : ((LOGT - RO) % 3 == 0) ? 3 : 4;   // ... of the distance-1 round
+  constexpr int NPO = 1 << RO;
+  constexpr int D1 = T >> RO, LOGD1 = LOGT - RO;  // outermost round
   constexpr int PT = T / NTHR;                    // points per thread
   constexpr int KF = Arith<H>::KF, KI = Arith<H>::KI, KP = Arith<H>::KP, KM = Arith<H>::KM, KANY = Arith<H>::KANY;
-  static_assert(NU >= 1 && LOGD1 >= 6, "row too short for this kernel");
+  static_assert(D1 == NTHR && LOGD1 >= 6 && (LOGD1 - RL) % 3 != 2, "row length does not fit this kernel's rounds");
   __shared__ __attribute__((aligned(16))) uint32_t lds[L::WORDS + 2 * LONG_TWL];
   uint32_t *sa = lds, *twf = lds + L::WORDS, *twi = twf + LONG_TWL;
   const Arith<H> M(A.ctx);
   for (int i = threadIdx.x; i < LONG_TWL; i += NTHR) { twf[i] = A.tw_fwd[i]; twi[i] = A.tw_inv[i]; }
+  // twiddles of the distance-1 rounds: the same for every unit, read once through the scalar cache
+  uint32_t ef[1 << RL], ei[1 << RL];
+  ef[0] = ei[0] = 0;
+#pragma unroll
+  for (int m = 1; m < (1 << RL); ++m) { ef[m] = A.tw_fwd[m]; ei[m] = A.tw_inv[m]; }
+  auto outer_dif = [&](uint32_t (&x)[NPO], const uint32_t (&w)[NPO]) {
+    if constexpr (RO == 4) r16_dif<H, false, Arith<H>::KROW, KF>(x, w, M); else r8_dif<H, false, false, Arith<H>::KROW, KF>(x, w, M);
+  };
 
   for (long long row = blockIdx.x; row < A.nrows; row += gridDim.x) {
     const uint32_t *pa = A.in0 + row * T, *pb = A.in1 + row * T;
-    // b's outermost-round points are fetched together with a's where the registers allow it; longer
-    // rows fetch each unit right before its butterflies (a row takes tens of microseconds, so the
+    // The table bases get an opaque scalar zero added in every trip: otherwise the per-thread table addresses (row
+    // invariant, 64 bits each) are hoisted out of the row loop and held in up to 60 vector registers, although a
+    // workgroup rarely sees a second row; this way they are scalar base + the 32-bit offsets the row data uses too.
+    unsigned zero = 0;
+    asm volatile("" : "+s"(zero));               // (an offset rather than the pointers: those must stay provably global)
+    const uint32_t *gtf = A.tw_fwd + zero, *gti = A.tw_inv + zero, *gpi = A.psi_in + zero, *gpo = A.psi_out + zero;
+    // b's outermost-round points are fetched together with a's where the registers allow it; the longest
+    // rows fetch them right before their butterflies (a row takes tens of microseconds, so the
     // exposed latency is small next to what spilled registers would cost)
-    constexpr bool EARLY_B = (NU == 1 && NTHR == 512);
-    uint32_t xb[8], w1[8];
+    constexpr bool EARLY_B = (NTHR == 512);
+    const unsigned g = threadIdx.x;                // the thread's unit of the outermost rounds: points g + q * D1
+    uint32_t xa[NPO], xb[NPO], w1[NPO];
     uint32_t ra[PT], rb[PT];
     w1[0] = 0;
     if (EARLY_B) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) xb[q] = pb[threadIdx.x + q * D1];
+      for (int q = 0; q < NPO; ++q) xb[q] = pb[g + q * D1];
     }
     __syncthreads();                               // previous row (and the twiddle copy) settled
     // ---- a: forward
-#pragma unroll 1
-    for (int u = 0; u < NU; ++u) {
-      const int g = threadIdx.x + u * NTHR;
-      uint32_t xa[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) xa[q] = pa[g + q * D1];
+    for (int q = 0; q < NPO; ++q) xa[q] = pa[g + q * D1];
 #pragma unroll
-      for (int m = 1; m < 8; ++m) w1[m] = A.tw_fwd[g + m * D1];
-      if constexpr (TWIST) {
+    for (int m = 1; m < NPO; ++m) w1[m] = gtf[g + m * D1];
+    if constexpr (TWIST) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xa[q] = M.mul(V<KANY>{xa[q]}, A.psi_in[g + q * D1]).v;
-      }
-      r8_dif<H, false, false, Arith<H>::KROW, KF>(xa, w1, M);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sa[L::padj(g + q * D1)] = xa[q];
+      for (int q = 0; q < NPO; ++q) xa[q] = M.mul(V<KANY>{xa[q]}, gpi[g + q * D1]).v;
     }
+    outer_dif(xa, w1);
+#pragma unroll
+    for (int q = 0; q < NPO; ++q) sa[L::padj(g + q * D1)] = xa[q];
     __syncthreads();
-    long_head<L, LOGD1, H>(sa, A.tw_fwd, twf, M);
-    long_edge<L, RL, false, H, KF, KP, PT>(sa, twf, M, ra);
+    long_head<L, LOGD1, RL, H>(sa, A.tw_fwd, twf, M);
+    long_edge<L, RL, false, H, KF, KP, PT>(sa, ef, M, ra);
     __syncthreads();
     // ---- b: forward
-#pragma unroll 1
-    for (int u = 0; u < NU; ++u) {
-      const int g = threadIdx.x + u * NTHR;
-      if (!EARLY_B) {
+    if (!EARLY_B) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xb[q] = pb[g + q * D1];
-        if (NU > 1) {
-#pragma unroll
-          for (int m = 1; m < 8; ++m) w1[m] = A.tw_fwd[g + m * D1];
-        }
-      }
-      if constexpr (TWIST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xb[q] = M.mul(V<KANY>{xb[q]}, A.psi_in[g + q * D1]).v;
-      }
-      r8_dif<H, false, false, Arith<H>::KROW, KF>(xb, w1, M);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sa[L::padj(g + q * D1)] = xb[q];
+      for (int q = 0; q < NPO; ++q) xb[q] = pb[g + q * D1];
     }
+    if constexpr (TWIST) {
+#pragma unroll
+      for (int q = 0; q < NPO; ++q) xb[q] = M.mul(V<KANY>{xb[q]}, gpi[g + q * D1]).v;
+    }
+    outer_dif(xb, w1);
+#pragma unroll
+    for (int q = 0; q < NPO; ++q) sa[L::padj(g + q * D1)] = xb[q];
     __syncthreads();
-    long_head<L, LOGD1, H>(sa, A.tw_fwd, twf, M);
-    long_edge<L, RL, false, H, KF, KP, PT>(sa, twf, M, rb);
+    long_head<L, LOGD1, RL, H>(sa, A.tw_fwd, twf, M);
+    long_edge<L, RL, false, H, KF, KP, PT>(sa, ef, M, rb);
     // ---- pointwise product, inverse
     if (A.scale) {
 #pragma unroll
@@ -882,32 +948,32 @@ __global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_mul_kernel(
 #pragma unroll
       for (int k = 0; k < PT; ++k) ra[k] = M.mul2(V<KP>{ra[k]}, V<KP>{rb[k]}).v;
     }
-    long_edge<L, RL, true, H, KM, KI, PT>(sa, twi, M, ra);   // each thread rewrites only the points it read
+    long_edge<L, RL, true, H, KM, KI, PT>(sa, ei, M, ra);   // each thread rewrites only the points it read
     __syncthreads();
-    long_tail<L, LOGT, H>(sa, A.tw_inv, twi, M);
+    long_tail<L, RL, LOGD1, H>(sa, A.tw_inv, twi, M);
     uint32_t *po = A.out + row * T;
-#pragma unroll 1
-    for (int u = 0; u < NU; ++u) {
-      const int g = threadIdx.x + u * NTHR;
-      uint32_t x[8], w[8];
-      w[0] = 0;
+    uint32_t x[NPO], w[NPO];
+    w[0] = 0;
 #pragma unroll
-      for (int m = 1; m < 8; ++m) w[m] = A.tw_inv[g + m * D1];
+    for (int m = 1; m < NPO; ++m) w[m] = gti[g + m * D1];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = sa[L::padj(g + q * D1)];
-      if constexpr (TWIST) {
-        r8_dit<H, false, KI, KANY>(x, w, M);
+    for (int q = 0; q < NPO; ++q) x[q] = sa[L::padj(g + q * D1)];
+    auto outer_dit = [&](auto kout) {
+      constexpr int KO = decltype(kout)::value;
+      if constexpr (RO == 4) r16_dit<H, false, KI, KO>(x, w, M); else r8_dit<H, false, KI, KO>(x, w, M);
+    };
+    if constexpr (TWIST) {
+      outer_dit(std::integral_constant<int, KANY>{});
 #pragma unroll
-        for (int q = 0; q < 8; ++q) po[g + q * D1] = M.canon(M.mul(V<KANY>{x[q]}, A.psi_out[g + q * D1]));
-      } else if (A.canon_out) {
-        r8_dit<H, false, KI, 1>(x, w, M);
+      for (int q = 0; q < NPO; ++q) po[g + q * D1] = M.canon(M.mul(V<KANY>{x[q]}, gpo[g + q * D1]));
+    } else if (A.canon_out) {
+      outer_dit(std::integral_constant<int, 1>{});
 #pragma unroll
-        for (int q = 0; q < 8; ++q) po[g + q * D1] = M.fix1(x[q]);
-      } else {
-        r8_dit<H, false, KI, KANY>(x, w, M);
+      for (int q = 0; q < NPO; ++q) po[g + q * D1] = M.fix1(x[q]);
+    } else {
+      outer_dit(std::integral_constant<int, KANY>{});
 #pragma unroll
-        for (int q = 0; q < 8; ++q) po[g + q * D1] = M.raw_out(x[q]);
-      }
+      for (int q = 0; q < NPO; ++q) po[g + q * D1] = M.raw_out(x[q]);
     }
   }
 }
