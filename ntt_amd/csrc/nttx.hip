@@ -110,6 +110,11 @@ static bool signed_rows(uint32_t p) {
   static const bool unsigned_only = [] { const char *e = getenv("NTTX_UNSIGNED"); return e && atoi(e) != 0; }();
   return p < (1u << 29) && !unsigned_only;
 }
+// ... and with sixteen multiples of headroom where 16p < 2^31 (NTTX_WIDE=0: the four-multiple kernels for every p < 2^29)
+static bool wide_rows(uint32_t p) {
+  static const bool narrow_only = [] { const char *e = getenv("NTTX_WIDE"); return e && atoi(e) == 0; }();
+  return p < (1u << 27) && signed_rows(p) && !narrow_only;
+}
 
 constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
 constexpr int kMinLongRow = 12, kMaxLongRow = 14;   // rows handled by one whole workgroup (longrow kernels)
@@ -330,8 +335,12 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
     static const int cap9 = env_int("NTTX_GRID_ROW", 8192);   // 4 rows per wave at batch 256: measured optimum
     const dim3 grid(grid_for(wgs, cap9));
     if constexpr (TWIST) {
-      if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((row_mul9_kernel<1, true, true>), grid, dim3(WG), 0, st, A);
+      if (H == 9 && wide_rows(A.ctx.p)) hipLaunchKernelGGL((row_mul9_kernel<17, true, true>), grid, dim3(WG), 0, st, A);
+      else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((row_mul9_kernel<1, true, true>), grid, dim3(WG), 0, st, A);
       else hipLaunchKernelGGL((row_mul9_kernel<H, true, true>), grid, dim3(WG), 0, st, A);
+    } else if (H == 9 && wide_rows(A.ctx.p)) {
+      if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<17, true>), grid, dim3(WG), 0, st, A);
+      else hipLaunchKernelGGL((row_mul9_kernel<17, false>), grid, dim3(WG), 0, st, A);
     } else if (H == 9 && signed_rows(A.ctx.p)) {
       // NTTX_ROW9_PROBE=1 / 2: the measurement builds of this kernel (one more LDS trip / 24 DPP moves per vector)
       static const int probe = env_int("NTTX_ROW9_PROBE", 0);
@@ -352,6 +361,7 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
 #define NTTX_LROW_CASE(K) case K: { \
       constexpr int NT_ = LongRowLayout<K>::NTHR, NTM_ = LongRowLayout<K, long_row_wide(K)>::NTHR; \
       if (MODE != ROW_MUL) hipLaunchKernelGGL((longrow_kernel<K, (MODE == ROW_MUL ? ROW_FWD : MODE), H>), dim3(grid), dim3(NT_), 0, st, A); \
+      else if (H == 9 && wide_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 16, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
       else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 0, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
       else hipLaunchKernelGGL((longrow_mul_kernel<K, H, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
       break; }

@@ -118,7 +118,7 @@ struct Arith {
   __device__ __forceinline__ uint32_t raw_out(uint32_t v) const { return v; }
 };
 
-// Signed classes (H = 1 and H = 0), used by the fused row kernels for p < 2^29, where 4p fits a signed 32-bit lane: V<K> holds an int32 of
+// Signed classes (H = 1 and H = 0; H = 17 and H = 16 below), used by the fused row kernels for p < 2^29, where 4p fits a signed 32-bit lane: V<K> holds an int32 of
 // magnitude below K*p (K <= 4).  Sums and differences need no offset, a signed REDC returns a value in
 // (-p, p), and any value is brought back into that range by one multiplication by 1 (three
 // instructions, the price of one and a half conditional subtractions) instead of a chain of them.
@@ -126,10 +126,18 @@ struct Arith {
 // ASM: the two multiply-adds of the REDC as inline assembly (the 512-point kernel, where the fixed
 // pairing is 1 % faster) or left to the compiler's scheduler (the long-row kernels, where inline
 // assembly costs hazard no-ops the scheduler cannot fill: 4-11 % slower).
-template <bool ASM>
+// HS = 16 (Arith<16>, p < 2^27): the same lanes with sixteen multiples of headroom.  A forward radix-8 unit then reduces
+// two of its outputs instead of six values, an inverse unit only the one input every output's additive chain starts from
+// (DIT_PRE), and the pointwise product one factor: 20 % fewer REDCs per 512-point product row than with four multiples
+// (18 % fewer VALU instructions, 10 % less time).  The column kernels gain nothing from it (forward 9 % fewer
+// instructions in the same time, inverse 5 % slower: its reductions become REDCs where the unsigned class spends
+// conditional subtractions), so they stay on the unsigned class for these moduli too.
+template <bool ASM, int HS_ = 4>
 struct SignedArith {
-  static constexpr int HS = 4;        // largest admissible bound
-  static constexpr int KM = 1, KF = 1, KI = 4, KP = 2, KANY = 4;
+  static constexpr int HS = HS_;      // largest admissible bound
+  static constexpr bool WIDE = HS >= 16;
+  static constexpr int KM = 1, KF = WIDE ? 2 : 1, KI = WIDE ? 8 : 4, KP = WIDE ? HS : 2, KANY = HS;
+  static constexpr bool DIT_PRE = WIDE;
   uint32_t p, pinv, one;
   int32_t negp;
   __device__ __forceinline__ SignedArith(const PrimeCtx &c) : p(c.p), pinv(0u - c.npinv), one(c.one), negp(-(int32_t)c.p) {}
@@ -188,14 +196,23 @@ struct SignedArith {
   template <int KOUT, int K>
   __device__ __forceinline__ uint32_t out(V<K> x) const { return reduce<KOUT>(x).v; }
   // The column passes around a fused row kernel run on the unsigned class: rows arrive below 2p, and a
-  // value left for the inverse column pass (any unsigned 32-bit word) gets 4p added to be non-negative.
+  // value left for the inverse column pass (any unsigned 32-bit word) gets HS*p added to be non-negative
+  // (2*HS*p < 2^32 in both classes).
   static constexpr int KROW = 2;
-  __device__ __forceinline__ uint32_t raw_out(uint32_t v) const { return v + 4u * p; }
+  __device__ __forceinline__ uint32_t raw_out(uint32_t v) const { return v + (uint32_t)HS * p; }
 };
 template <>
 struct Arith<1> : SignedArith<true> { __device__ __forceinline__ Arith(const PrimeCtx &c) : SignedArith<true>(c) {} };
 template <>
 struct Arith<0> : SignedArith<false> { __device__ __forceinline__ Arith(const PrimeCtx &c) : SignedArith<false>(c) {} };
+template <>
+struct Arith<16> : SignedArith<false, 16> { __device__ __forceinline__ Arith(const PrimeCtx &c) : SignedArith<false, 16>(c) {} };
+template <>
+struct Arith<17> : SignedArith<true, 16> { __device__ __forceinline__ Arith(const PrimeCtx &c) : SignedArith<true, 16>(c) {} };   // (512-point kernel: 2 % faster)
+template <class A, class = void>
+struct dit_pre_of { static constexpr bool value = false; };
+template <class A>
+struct dit_pre_of<A, std::enable_if_t<A::DIT_PRE>> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------
 // Radix-8 / 4 / 2 units on registers: stages at point distances 4D, 2D, D.
@@ -233,7 +250,11 @@ __device__ __forceinline__ void r8_dif(uint32_t (&x)[8], const uint32_t (&w)[8],
 
 template <int H, bool UNIT_D1, int KIN = Arith<H>::KI, int KOUT = Arith<H>::KI>
 __device__ __forceinline__ void r8_dit(uint32_t (&x)[8], const uint32_t (&w)[8], const Arith<H> &M) {
-  const V<KIN> i0{x[0]}, i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
+  // Every output is x[0] plus or minus three products, so with headroom to spare reducing x[0] alone bounds them all by
+  // four multiples (the other inputs are multiplied before they are added to anything).
+  constexpr bool PRE = dit_pre_of<Arith<H>>::value && !UNIT_D1 && KOUT >= 4 && KIN + 3 > KOUT;
+  const V<KIN> i1{x[1]}, i2{x[2]}, i3{x[3]}, i4{x[4]}, i5{x[5]}, i6{x[6]}, i7{x[7]};
+  const auto i0 = [&] { if constexpr (PRE) return M.template reduce<KOUT - 3>(V<KIN>{x[0]}); else return V<KIN>{x[0]}; }();
   // distance D
   const auto p01 = [&] { if constexpr (UNIT_D1) return M.bf1(i0, i1); else return M.dit(i0, i1, w[1]); }();
   const auto p23 = [&] { if constexpr (UNIT_D1) return M.bf1(i2, i3); else return M.dit(i2, i3, w[1]); }();
@@ -283,7 +304,9 @@ __device__ __forceinline__ void r16_dif(uint32_t (&x)[16], const uint32_t (&w)[1
 }
 template <int H, bool UNIT_D1, int KIN, int KOUT>
 __device__ __forceinline__ void r16_dit(uint32_t (&x)[16], const uint32_t (&w)[16], const Arith<H> &M) {
-  constexpr int KI = Arith<H>::KI;
+  // bound left by the two radix-8 halves: one below KOUT where the class can hold it there for free, so that the last
+  // stage's sums need no reduction
+  constexpr int KI = (dit_pre_of<Arith<H>>::value && KOUT > 4 && KOUT - 1 < Arith<H>::KI) ? KOUT - 1 : Arith<H>::KI;
   uint32_t lo[8], hi[8], w8[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { lo[j] = x[j]; hi[j] = x[j + 8]; w8[j] = w[j]; }

@@ -228,6 +228,38 @@ def _dev_cyclic(nttx, a, b, p):
     return dc.cpu().numpy().view(np.uint32)
 
 
+@pytest.mark.parametrize("p", (132120577, 104857601, 7340033))
+def test_sixteen_multiple_signed_rows(nttx, oracle, p):
+    """Moduli below 2^27 run their fused row kernels on signed lanes with sixteen multiples of headroom: the 512-point
+    kernel (single pass and behind a column pass), the long-row kernels with radix-8 and radix-16 rounds, and a three-pass
+    length, on random operands and on the operands that drive every sum to its bound (all p - 1, and p - 1 against 1,
+    p - 1 alternating).  132120577 = 63 * 2^21 + 1 is the largest such modulus below 2^27 with these lengths; 3 is a
+    quadratic residue there, so the reference's transform (root 3, main.cc:161) does not exist for it and the expected
+    product is the folded linear product of the reference's four-prime CRT route instead."""
+    def expected(x, y):
+        if p != 132120577:
+            return oracle.ntt_compute(x, y, p)
+        lin = np.zeros(2 * len(x), dtype=np.uint64)
+        lin[: 2 * len(x) - 1] = oracle.poly_multiply_crt(x.astype(np.uint64), y.astype(np.uint64), p)
+        return ((lin[: len(x)] + lin[len(x):]) % np.uint64(p)).astype(np.uint32)
+
+    for logn, batch in ((9, 3), (11, 2), (12, 2), (13, 2), (14, 1), (18, 1), (20, 1), (21, 1)):
+        n = 1 << logn
+        if (p - 1) % n or (p == 132120577 and logn > 20):
+            continue
+        a = rand(oracle, n * batch, 700 + logn, p).astype(np.uint32).reshape(batch, n)
+        b = rand(oracle, n * batch, 800 + logn, p).astype(np.uint32).reshape(batch, n)
+        a[0, :] = p - 1
+        b[0, :] = p - 1
+        if batch > 1:
+            a[1, :] = p - 1
+            b[1, 0::2] = 1
+            b[1, 1::2] = p - 1
+        got = _dev_cyclic(nttx, a, b, p)
+        for i in range(batch):
+            assert np.array_equal(got[i], expected(a[i], b[i])), (p, logn, i)
+
+
 @pytest.mark.parametrize("p,logn", [(469762049, 21), (469762049, 22), (469762049, 23), (998244353, 22), (1224736769, 23)])
 def test_long_row_two_pass(nttx, oracle, p, logn):
     """One column pass around long rows (2^12 .. 2^14 points): cyclic products of length 2^21 .. 2^23
