@@ -529,7 +529,7 @@ def run_single(R, args):
         "bytes_per_step": {k: w * 4 * L * B for k, w in words.items()}, "launches_per_step": {k: 1 for k in words},
         "prof": prof, "roofline_kind": "single",
         "extra": {"us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6, "us_per_mult_batch_1": lat1_us,
-                  "pipeline_model": {"what": "a MODEL, not traffic: the survey's two-HBM-passes-per-transform byte count "
+                  "pipeline_model": {"what": "a MODEL, not traffic: a two-HBM-passes-per-transform byte count "
                                              "(52 L per product) times the measured rate; the kernels move 32 L",
                                      "model_bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "bytes_per_mult_moved": 32 * L,
                                      "model_GBs_per_gpu": MODEL_BYTES_PER_L * L * (mults / R.world / elapsed) / 1e9,

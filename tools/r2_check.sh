@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 check on the GPU box: tests, headline bench, the other workloads on one rank, two-rank rehearsals on one GPU
+# check on the GPU box: tests, headline bench, the other workloads on one rank, two-rank rehearsals on one GPU
 set -o pipefail
 out=gpurun_out/r2a; mkdir -p $out
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 record run on the GPU box: rocprofv3 passes over the headline bench, then one bench line per workload
+# record run on the GPU box: rocprofv3 passes over the headline bench, then one bench line per workload
 set -o pipefail
 out=gpurun_out/r2final; mkdir -p $out
 bash tools/prof.sh r2 > $out/prof.log 2>&1 || { tail -20 $out/prof.log; exit 1; }
