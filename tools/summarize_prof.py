@@ -63,12 +63,12 @@ for n, c, a, *_ in stats:
     lines.append(f"| `{n}` | {f:.0f} | {w:.0f} | {hbm/1e6:.1f} MB | {mean(s['SQ_INSTS_VALU'])/1e6:.2f} M | {mean(s['SQ_INSTS_LDS'])/1e6:.2f} M | "
                  f"{mean(s['SQ_LDS_BANK_CONFLICT'])/1e6:.2f} M / {mean(s['SQ_LDS_IDX_ACTIVE'])/1e6:.2f} M | {mean(s['SQ_WAVE_CYCLES'])/1e6:.1f} M | "
                  f"{mean(s2['SQ_WAIT_ANY'])/1e6:.1f} M | {mean(s2['SQ_WAIT_INST_ANY'])/1e6:.1f} M | {mean(s2['GRBM_GUI_ACTIVE'])/8/1e3:.1f} k cycles |")
-lines += ["", "Derived per launch (1024 SIMDs; VALU issue cost measured at about 4.6 cycles per wave instruction in butterfly code):", ""]
+lines += ["", "Derived per launch (1024 SIMDs; the VALU share is a MODEL: instructions x 4.6 cycles, the issue cost of butterfly code measured alone; ablation builds show the column kernels bound by their access pattern instead, profiles/r2_pitch_experiment.md):", ""]
 for n, c, a, *_ in stats:
     valu = mean(sq[n]["SQ_INSTS_VALU"])
     cyc = mean(sq2[n]["GRBM_GUI_ACTIVE"]) / 8
     if valu == valu and cyc == cyc:
-        lines.append(f"- `{n}`: effective clock {cyc / (a * 1e-9) / 1e9:.2f} GHz; VALU issue share ≈ {valu * 4.6 / 1024 / cyc * 100:.0f} % of kernel cycles; "
+        lines.append(f"- `{n}`: effective clock {cyc / (a * 1e-9) / 1e9:.2f} GHz; VALU issue share by that model ≈ {valu * 4.6 / 1024 / cyc * 100:.0f} % of kernel cycles; "
                      f"HBM {traffic.get([v for k, v in kind.items() if n.startswith(k)][0], float('nan')) / (a * 1e-9) / 1e12:.2f} TB/s")
 open(os.path.join("profiles", f"{tag}_rocprof.md"), "w").write("\n".join(lines) + "\n")
 # the records bench.py quotes: tagged with a hash of the kernel sources, refused there once the kernels change
