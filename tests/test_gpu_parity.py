@@ -593,7 +593,8 @@ def test_device_linear_product_skips_padding(nttx, oracle, n):
 
 _NEGA = ([(469762049, k, 3) for k in range(1, 17)] + [(998244353, k, 2) for k in (4, 8, 9, 10, 12, 14, 15, 17)]
          + [(1224736769, k, 2) for k in (6, 9, 11, 13, 16)] + [(469762049, 18, 2), (469762049, 20, 1), (998244353, 21, 1),
-                                                               (469762049, 24, 1)])
+                                                               (469762049, 24, 1)]
+         + [(104857601, k, 2) for k in (9, 11, 13, 14, 16)] + [(7340033, 9, 2), (7340033, 12, 1)])   # sixteen-multiple signed rows
 
 
 @pytest.mark.parametrize("p,log_len,batch", _NEGA)
