@@ -86,6 +86,20 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
       return colfail(NTTX_ERANGE, "pieces layout needs a plain column pass");
     }
   }
+  // 2^6-point passes (products of 2^15 points) run on tiles of 64 columns (256-byte row segments) instead of 32: these
+  // passes run at the rate of their access pattern, and a bare copy of the wider shape moves 10 % more (forward pass
+  // 0.197 -> 0.170 ms, inverse 0.114 -> 0.103 ms per 2^26 points, the step 4.6 % faster).  At 2^7 and 2^8 points the
+  // same change makes the column kernels 1 - 7 % faster and the step no faster (the row kernel between them then runs
+  // that much slower: the part holds a power budget, not a clock).  NTTX_COL_SEG256=0 keeps 128-byte segments.
+  if constexpr (!FS2) {
+    static const int seg256 = env_int("NTTX_COL_SEG256", 1);
+    if (seg256 && wide && logT == 6 && A.logS >= 6 && !A.psi && tiles >= 1024) {
+      const long long t64 = A.nblocks << (A.logS - 6);
+      hipLaunchKernelGGL((col_kernel<6, INV, H, 6, 256, ZHI, false>), dim3(grid_for(t64, cap), 1, nvec), dim3(256), 0, st, A);
+      if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
+      return 0;
+    }
+  }
   if (lc < 4) {
     if (lc == 3) { hipLaunchKernelGGL((col_kernel<9, INV, H, 3, 512, ZHI, false>), dim3(grid, 1, nvec), dim3(512), 0, st, A); }
     else { hipLaunchKernelGGL((col_kernel<9, INV, H, 2, 256, ZHI, false>), dim3(grid, 1, nvec), dim3(256), 0, st, A); }
