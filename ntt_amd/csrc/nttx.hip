@@ -822,7 +822,9 @@ static int dev_negacyclic_multiply(Context *cx, const uint32_t *a, const uint32_
   // one- and two-pass plans apply psi^i inside their first and last pass (two-pass plans use full-line column tiles,
   // the only shape with a twisted variant); three-pass plans go through separate element-wise passes
   static const bool unfused = [] { const char *e = getenv("NTTX_TWIST_UNFUSED"); return e && atoi(e) != 0; }();
-  if (pl->npass <= 2 && !unfused) return dev_cyclic_multiply(cx, pl, a, b, c, batch, st, 0, tw->fwd, tw->inv);
+  // (a two-pass plan whose column pass is longer than 2^9 points has no twisted column kernel: plans chosen under NTTX_LONGROW=0)
+  const bool fusable = pl->npass == 1 || (pl->npass == 2 && pl->lt[0] <= 9 && pl->logL - pl->lt[0] >= 5);
+  if (fusable && !unfused) return dev_cyclic_multiply(cx, pl, a, b, c, batch, st, 0, tw->fwd, tw->inv);
   const long long len = 1ll << logL;
   const size_t vec = (size_t)batch * len * 4;
   if (int rc = cx->pa.ensure(vec)) return rc;
