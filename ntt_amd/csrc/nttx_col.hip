@@ -24,15 +24,16 @@ template <bool INV, int H, bool ZHI, bool FS2>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
   // Few tiles (one product, or a handful): full-line tiles would leave most of the 256 CUs idle while each of the busy
-  // ones works through 16384 points, so 2^9-point passes switch to tiles of 8 or 4 columns with one radix-8 unit per
-  // thread and round, until about 256 workgroups exist (one 2^18-point product: 7.8 -> about 2.5 us per pass).
+  // ones works through its whole tile, so passes of 2^6 .. 2^9 points switch to tiles of 8 or 4 columns with one radix-8
+  // unit per thread and round, until about 256 workgroups exist (one 2^18-point product: 7.8 -> about 2.5 us per pass).
   // NTTX_COL_NARROW=0 keeps full-line tiles (A/B measurements), 2 or 3 forces a width.
   int lc = wide ? 5 : 4;
-  if (wide && logT == 9 && !FS2 && !A.psi && !A.piece_stride) {
+  if (wide && logT >= 6 && !FS2 && !A.psi && !A.piece_stride) {
     static const int narrow = env_int("NTTX_COL_NARROW", -1);
+    const int lcmin = logT == 6 ? 3 : 2;       // (a tile of 2^6 rows x 4 columns would be half a wavefront of units)
     long long w = (A.nblocks << (A.logS - 5)) * nvec;
-    if (narrow == 2 || narrow == 3) lc = narrow;
-    else if (narrow != 0) while (lc > 2 && w < 192) { --lc; w <<= 1; }
+    if (narrow == 2 || narrow == 3) lc = std::max(narrow, lcmin);
+    else if (narrow != 0) while (lc > lcmin && w < 192) { --lc; w <<= 1; }
     if (lc == 4) lc = 3;                       // (the 16-column shape keeps four units per thread: no gain there)
   }
   const long long tiles = A.nblocks << (A.logS - lc);
@@ -101,8 +102,18 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
     }
   }
   if (lc < 4) {
-    if (lc == 3) { hipLaunchKernelGGL((col_kernel<9, INV, H, 3, 512, ZHI, false>), dim3(grid, 1, nvec), dim3(512), 0, st, A); }
-    else { hipLaunchKernelGGL((col_kernel<9, INV, H, 2, 256, ZHI, false>), dim3(grid, 1, nvec), dim3(256), 0, st, A); }
+    if constexpr (!FS2) {
+#define NTTX_COLN_CASE(K, LC, NT) \
+      hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, false>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+      switch (logT * 4 + lc) {                   // one radix-8 unit per thread: 2^(logT + lc - 3) threads
+        case 6 * 4 + 3: NTTX_COLN_CASE(6, 3, 64)
+        case 7 * 4 + 3: NTTX_COLN_CASE(7, 3, 128)  case 7 * 4 + 2: NTTX_COLN_CASE(7, 2, 64)
+        case 8 * 4 + 3: NTTX_COLN_CASE(8, 3, 256)  case 8 * 4 + 2: NTTX_COLN_CASE(8, 2, 128)
+        case 9 * 4 + 3: NTTX_COLN_CASE(9, 3, 512)  case 9 * 4 + 2: NTTX_COLN_CASE(9, 2, 256)
+        default: return colfail(NTTX_ERANGE, "column pass of this size has no narrow-tile variant");
+      }
+#undef NTTX_COLN_CASE
+    }
     if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
     return 0;
   }
