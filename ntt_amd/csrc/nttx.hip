@@ -342,11 +342,13 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
       if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<17, true>), grid, dim3(WG), 0, st, A);
       else hipLaunchKernelGGL((row_mul9_kernel<17, false>), grid, dim3(WG), 0, st, A);
     } else if (H == 9 && signed_rows(A.ctx.p)) {
-      // NTTX_ROW9_PROBE=1 / 2: the measurement builds of this kernel (one more LDS trip / 24 DPP moves per vector)
-      static const int probe = env_int("NTTX_ROW9_PROBE", 0);
       if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<1, true>), grid, dim3(WG), 0, st, A);
-      else if (probe == 1) hipLaunchKernelGGL((row_mul9_kernel<1, false, false, 1>), grid, dim3(WG), 0, st, A);
-      else if (probe == 2) hipLaunchKernelGGL((row_mul9_kernel<1, false, false, 2>), grid, dim3(WG), 0, st, A);
+#ifdef NTTX_BUILD_PROBES
+      // measurement builds only (make CXXFLAGS+=-DNTTX_BUILD_PROBES): NTTX_ROW9_PROBE=1 / 2 selects the probe variants of
+      // this kernel (one more LDS trip / 24 DPP moves per vector); the shipped library does not contain them
+      else if (env_int("NTTX_ROW9_PROBE", 0) == 1) hipLaunchKernelGGL((row_mul9_kernel<1, false, false, 1>), grid, dim3(WG), 0, st, A);
+      else if (env_int("NTTX_ROW9_PROBE", 0) == 2) hipLaunchKernelGGL((row_mul9_kernel<1, false, false, 2>), grid, dim3(WG), 0, st, A);
+#endif
       else hipLaunchKernelGGL((row_mul9_kernel<1, false>), grid, dim3(WG), 0, st, A);
     } else if (A.canon_out) hipLaunchKernelGGL((row_mul9_kernel<H, true>), grid, dim3(WG), 0, st, A);
     else hipLaunchKernelGGL((row_mul9_kernel<H, false>), grid, dim3(WG), 0, st, A);
