@@ -305,8 +305,12 @@ class CrtSharded:
     """rank r: prime group r % Gp owns the moduli k with k % Gp == r % Gp, batch group r // Gp owns
     a contiguous share of the products.  The ranks of a batch group exchange residue slices once."""
 
-    def __init__(self, comm, engine):
+    def __init__(self, comm, engine, force_exchange=False):
+        """force_exchange: take the exchange route even where one rank owns every prime (the sliced send buffer, the
+        all-to-all and the all-gather then run over a group of one: a way to drive the multi-rank code path, collective
+        library included, on a single GPU)."""
         self.comm, self.engine = comm, engine
+        self.force_exchange = force_exchange
         self.gp, self.gb = crt_layout(comm.world)
         gp = self.gp
         self.pr, self.br = comm.rank % gp, comm.rank // gp
@@ -327,7 +331,7 @@ class CrtSharded:
         # product ("sum % M", main.cc:330) - the same check, and the same NTTX_ERANGE, as the single-GPU entry point
         from . import api
         api.crt_primes_for(p, n)
-        if gp == 1:
+        if gp == 1 and not self.force_exchange:
             res = self.engine.crt_residues(a, b, n, self.mask)          # [nown][nb][len]
             full = self.engine.crt_recombine([res[k] for k in range(CRT_PRIME_COUNT)], p)
             return full[:, : 2 * n - 1] if gather else full
@@ -359,7 +363,10 @@ class FourStepSharded:
     (T = 2^log_t); rank g holds columns g*S/G .. (g+1)*S/G - 1 as a dense [T][S/G] int32 slab, for
     inputs and for the result alike.  `slab_of` / `place_slab` convert from and to whole vectors."""
 
-    def __init__(self, comm, engine, log_len, p, log_t=None):
+    def __init__(self, comm, engine, log_len, p, log_t=None, force_exchange=False):
+        """force_exchange: a single rank also goes through the three exchanges and the pieces-layout row products (over a
+        group of one), so the multi-rank code path can be driven on a single GPU."""
+        self.force_exchange = force_exchange
         g = comm.world
         if g & (g - 1):
             raise ValueError("the number of ranks must be a power of two")
@@ -393,7 +400,7 @@ class FourStepSharded:
 
     def _to_slab(self, y):
         g = self.comm.world
-        if g == 1:
+        if g == 1 and not self.force_exchange:
             return y
         z = y.view(self.rows, g, self.cols).permute(1, 0, 2).contiguous()    # [dest][rows][cols]
         return self.comm.all_to_all(z).view(self.T, self.cols)
@@ -403,7 +410,7 @@ class FourStepSharded:
         2^(log_len-1) on (a linear product), so the upper half of the rows is not read.
         Returns this rank's slab of the product."""
         e, L, t, p = self.engine, self.log_len, self.log_t, self.p
-        if self.comm.world == 1:
+        if self.comm.world == 1 and not self.force_exchange:
             e.colpass(xa, L, t, self.col0, p, False, zero_hi)
             e.colpass(xb, L, t, self.col0, p, False, zero_hi)
             ya, yb = xa, xb

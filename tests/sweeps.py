@@ -175,6 +175,21 @@ def suite_col(nttx, O):
             linear(nttx, O, p, (1 << (k - 1)) - 5, 64, seed=k + 1)
 
 
+def suite_col_lite(nttx, O):
+    """The shapes of suite_col on fewer moduli and with the oracle on a sample of the larger batches (the measurement
+    switches get this one: each of them is a child process of its own)."""
+    for p in (P9, P2, PW):
+        for k in (15, 16, 17, 18):
+            cyclic(nttx, O, p, k, 1, seed=10 * k)
+            linear(nttx, O, p, (1 << (k - 1)) - 777, 3, seed=20 * k)
+    sample = (0, 1, 31, 32, 62, 63)
+    for p in (P9, P4, P2):
+        cyclic(nttx, O, p, 15, 64, seed=64, check=sample)
+        linear(nttx, O, p, 12345, 64, seed=66, check=sample)
+    cyclic(nttx, O, P9, 16, 64, seed=16, check=sample)
+    linear(nttx, O, P2, (1 << 16) - 5, 64, seed=17, check=sample)
+
+
 def suite_col_big(nttx, O):
     """4096 products of 2^15 points per call: the oracle on a sample, the evaluations at 1 and -1 on every product."""
     sample = (0, 1, 63, 64, 1023, 1024, 2047, 3000, 4094, 4095)
@@ -223,7 +238,7 @@ def suite_d64(nttx, O):
             negacyclic64(nttx, O, p, k, 2, seed=k)
 
 
-SUITES = {"col": suite_col, "col_big": suite_col_big, "rows": suite_rows, "crt": suite_crt, "d64": suite_d64}
+SUITES = {"col": suite_col, "col_lite": suite_col_lite, "col_big": suite_col_big, "rows": suite_rows, "crt": suite_crt, "d64": suite_d64}
 
 
 def main(argv):

@@ -22,12 +22,12 @@ def test_default_dispatch(nttx, oracle, suite):
 
 # (environment, suites): one child process each
 SWITCHES = [
-    ({"NTTX_COL_SEG256": "0"}, ["col"]),                       # 2^6-point passes on 128-byte tiles at every batch
-    ({"NTTX_COL_NARROW": "0"}, ["col"]),                       # full-line tiles for small launches too
-    ({"NTTX_COL_NARROW": "2"}, ["col"]),                       # 4-column tiles forced
-    ({"NTTX_COL_NARROW": "3"}, ["col"]),                       # 8-column tiles forced
-    ({"NTTX_GRID_COL": "5", "NTTX_GRID_COLI": "3"}, ["col"]),  # few workgroups: each strides over many tiles
-    ({"NTTX_UNSIGNED": "1"}, ["rows", "col"]),                 # unsigned lanes in the fused row kernels
+    ({"NTTX_COL_SEG256": "0"}, ["col_lite"]),                       # 2^6-point passes on 128-byte tiles at every batch
+    ({"NTTX_COL_NARROW": "0"}, ["col_lite"]),                       # full-line tiles for small launches too
+    ({"NTTX_COL_NARROW": "2"}, ["col_lite"]),                       # 4-column tiles forced
+    ({"NTTX_COL_NARROW": "3"}, ["col_lite"]),                       # 8-column tiles forced
+    ({"NTTX_GRID_COL": "5", "NTTX_GRID_COLI": "3"}, ["col_lite"]),  # few workgroups: each strides over many tiles
+    ({"NTTX_UNSIGNED": "1"}, ["rows", "col_lite"]),                 # unsigned lanes in the fused row kernels
     ({"NTTX_WIDE": "0"}, ["rows"]),                            # four-multiple signed rows for moduli below 2^27 too
     ({"NTTX_LONGROW": "0"}, ["rows"]),                         # plans without one-workgroup rows
     ({"NTTX_LONGROW": "1"}, ["rows"]),

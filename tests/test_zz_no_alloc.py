@@ -66,9 +66,9 @@ def test_static_scratch_entry_point_limits(nttx, oracle):
     with pytest.raises(nttx.NttxError) as e:
         nttx.dev_poly_multiply_u32_static(big.data_ptr(), big.data_ptr(), big.data_ptr(), 131072, P, 17, st)
     assert e.value.code == -2 and "static scratch" in str(e.value)
-    # tables that were never built (no other test multiplies 2^19-point products modulo 7340033): the call may not build them
+    # tables that were never built (13631489 = 13 * 2^20 + 1 is a modulus no other test uses): the call may not build them
     with pytest.raises(nttx.NttxError) as e:
-        nttx.dev_poly_multiply_u32_static(big.data_ptr(), big.data_ptr(), big.data_ptr(), 200000, 7340033, 1, st)
+        nttx.dev_poly_multiply_u32_static(big.data_ptr(), big.data_ptr(), big.data_ptr(), 200000, 13631489, 1, st)
     assert e.value.code == -5 and "set-up" in str(e.value)
     # the largest admissible call: 16 products of length 2^18 fill the scratch exactly
     a, b, da, db = _inputs(torch, oracle, 16, 131072, 1 << 18, 41)
