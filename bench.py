@@ -60,8 +60,9 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
-def recorded_counters(name, kernel):
-    """profiles/<name>.json = {"kernel_source_tag": ..., "kernels": {kind: value}}; None when absent or stale."""
+def recorded_counters(name, workload, kernel=None):
+    """profiles/<name>.json = {"kernel_source_tag": ..., "workloads": {workload: {"kernels": {kind: value}, ...}}}.
+    Returns (value of one kind, or the whole workload record when kernel is None; state); None when absent or stale."""
     path = os.path.join(ROOT, "profiles", name + ".json")
     try:
         rec = json.load(open(path))
@@ -69,7 +70,13 @@ def recorded_counters(name, kernel):
         return None, "absent"
     if rec.get("kernel_source_tag") != kernel_source_tag():
         return None, "stale (kernel sources changed since it was measured)"
-    return rec.get("kernels", {}).get(kernel), "current"
+    w = rec.get("workloads", {}).get(workload)
+    if w is None:
+        return None, "not recorded for this workload"
+    return (w if kernel is None else w.get("kernels", {}).get(kernel)), "current"
+
+
+VALU_CYCLES_PER_INSTRUCTION = 4.6     # butterfly code measured alone on gfx950: one wave64 VALU instruction per ~4.6 cycles per SIMD
 
 
 # ------------------------------------------------------------------------------------------------
@@ -407,8 +414,9 @@ class Rank:
             self.dist.destroy_process_group()
 
 
-def roofline_of(prof, bytes_per_step, launches_per_step, extra=None):
-    """Dominant kernel kind (largest share of the event-timed device time) against the HBM bytes it moves.
+def roofline_of(prof, bytes_per_step, launches_per_step, workload=None):
+    """Dominant kernel kind (largest share of the event-timed device time) against the HBM bytes it moves, plus the
+    whole step, the counter records of this workload (HBM traffic, VALU instructions) and the bound they name.
     prof: {kind: (total ms, launches)}; bytes_per_step / launches_per_step: {kind: ...} of this rank."""
     kern = {k: v for k, v in prof.items() if v[1] > 0}
     if not kern:
@@ -418,39 +426,57 @@ def roofline_of(prof, bytes_per_step, launches_per_step, extra=None):
     avg_s = ms / launches * 1e-3
     per_launch = bytes_per_step.get(dom, 0) / max(1, launches_per_step.get(dom, 1))
     achieved = per_launch / avg_s / 1e9
-    traffic, traffic_state = recorded_counters("traffic", dom) if extra == "single" else (None, "not recorded for this workload")
+    traffic, traffic_state = recorded_counters("traffic", workload, dom)
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_record": traffic_state,
             "bytes": "HBM bytes the kernel moves per launch (its reads + writes, each word once)",
-            "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms / launches, "launches_timed": launches}
+            "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms / launches, "launches_timed": launches,
+            "timing": "HIP events on the launch stream around every kernel of every 4th timed step; a step whose kernels are "
+                      "bracketed by events runs 1-2 % slower than ms_per_step (an event record keeps the next kernel from "
+                      "starting while the previous one drains), so these fractions are slightly conservative"}
     # whole step: every kernel's moved bytes over the sum of the kernels' event-timed durations
     tot_b = sum(bytes_per_step.get(k, 0) for k in kern)
-    tot_s = sum(kern[k][0] / kern[k][1] * launches_per_step.get(k, 1) for k in kern) * 1e-3
+    per_kind_s = {k: kern[k][0] / kern[k][1] * launches_per_step.get(k, 1) * 1e-3 for k in kern}
+    tot_s = sum(per_kind_s.values())
     roof["whole_step"] = {"moved_bytes_per_step": tot_b, "kernel_ms_per_step": tot_s * 1e3, "achieved": tot_b / tot_s / 1e9,
                           "frac": tot_b / tot_s / 1e9 / HBM_PEAK_GBS}
-    if extra == "single":
-        insts, state = recorded_counters("valu", dom)
-        if insts:
-            # integer-VALU issue: a SIMD issues a wave64 instruction of this path in 2.5 (add/sub) to 4.5 (64-bit
-            # multiply-add) cycles; the figure below is cycles the kernel took per instruction it issued, per SIMD
-            cyc = SIMDS * CLOCK_GHZ * 1e9 * avg_s / insts
-            clk = None
-            try:
-                clk = json.load(open(os.path.join(ROOT, "profiles", "valu.json"))).get("clock_GHz", {}).get(dom)
-            except Exception:                              # noqa: BLE001
-                pass
-            roof["valu"] = {"wave_instructions_per_launch": insts, "record": state,
-                            "simd_cycles_per_instruction_at_2.4GHz": cyc,
-                            "issue_rate_frac_of_one_per_cycle": 1.0 / cyc,
-                            "clock_GHz_in_profile": clk,
-                            "simd_cycles_per_instruction_at_profiled_clock": (SIMDS * clk * 1e9 * avg_s / insts) if clk else None,
-                            "issue_busy_frac_at_4.6_cycles_per_instruction": (insts * 4.6 / (SIMDS * clk * 1e9 * avg_s)) if clk else None,
-                            "note": "SQ_INSTS_VALU of profiles/valu.json over 1024 SIMDs x 2.4 GHz x the live launch time; "
-                                    "butterfly code measured alone issues at about 4.6 cycles per instruction per SIMD "
-                                    "(64-bit multiply-adds 4.5, 32-bit multiplies 4.2, adds 2.5), so values near 4.6-5 mean "
-                                    "the kernel is bound by integer-VALU issue, not by HBM"}
-        else:
-            roof["valu"] = {"record": state}
+    wrec, wstate = recorded_counters("traffic", workload)
+    if wrec:
+        t = sum(wrec["kernels"].get(k, 0) * launches_per_step.get(k, 1) for k in kern)
+        roof["whole_step"]["traffic_bytes_per_step"] = t
+        roof["whole_step"]["traffic_over_moved"] = t / tot_b if tot_b else None
+    vrec, vstate = recorded_counters("valu", workload)
+    if vrec:
+        insts_k, clk_k = vrec.get("kernels", {}), vrec.get("clock_GHz", {})
+        insts, clk = insts_k.get(dom), clk_k.get(dom)
+        valu = {"record": vstate, "model_cycles_per_instruction": VALU_CYCLES_PER_INSTRUCTION,
+                "note": "SQ_INSTS_VALU (wave-level vector instructions) per launch from the tagged counter record of this "
+                        "workload over 1024 SIMDs x the clock held in the profile x the live launch time; butterfly code "
+                        "measured alone issues one instruction per about 4.6 cycles per SIMD (64-bit multiply-adds 4.5, "
+                        "32-bit multiplies 4.2, adds 2.5), so issue_busy_frac near 1 means the kernel is bound by integer-VALU "
+                        "issue, not by HBM"}
+        if insts and clk:
+            valu.update({"wave_instructions_per_launch": insts, "clock_GHz_in_profile": clk,
+                         "simd_cycles_per_instruction_at_2.4GHz": SIMDS * CLOCK_GHZ * 1e9 * avg_s / insts,
+                         "simd_cycles_per_instruction_at_profiled_clock": SIMDS * clk * 1e9 * avg_s / insts,
+                         "issue_busy_frac": insts * VALU_CYCLES_PER_INSTRUCTION / (SIMDS * clk * 1e9 * avg_s)})
+        # the whole step on the same model: every kind's instructions at the clock it ran at in the profile
+        busy_s = sum(insts_k[k] * launches_per_step.get(k, 1) * VALU_CYCLES_PER_INSTRUCTION / (SIMDS * clk_k[k] * 1e9)
+                     for k in kern if insts_k.get(k) and clk_k.get(k))
+        if busy_s:
+            valu["whole_step"] = {"wave_instructions_per_step": sum(insts_k[k] * launches_per_step.get(k, 1) for k in kern if insts_k.get(k)),
+                                  "issue_busy_ms_per_step_by_model": busy_s * 1e3, "kernel_ms_per_step": tot_s * 1e3,
+                                  "issue_busy_frac": busy_s / tot_s}
+        roof["valu"] = valu
+        # the bound the evidence names: the larger of the two fractions (HBM bytes moved over the spec peak, VALU issue by
+        # the model above), for the dominant kernel
+        if valu.get("issue_busy_frac", 0) > roof["frac"]:
+            roof["bound"] = "valu"
+            roof["bound_note"] = ("integer-VALU issue: the dominant kernel's vector instructions fill %.0f %% of its SIMD cycles by "
+                                  "the issue model while its HBM bytes are %.0f %% of the 8 TB/s peak; achieved / peak / frac stay "
+                                  "the HBM figures (no MFMA on this path)" % (100 * valu["issue_busy_frac"], 100 * roof["frac"]))
+    else:
+        roof["valu"] = {"record": vstate}
     return roof, {k: v[0] / v[1] for k, v in kern.items()}
 
 
@@ -494,14 +520,15 @@ def run_single(R, args):
 
     copy_gbs = lat1_us = None
     if R.rank == 0 and not args.no_context:
-        # two context figures, outside the timed region: what a plain device-to-device copy of the same buffers reaches
-        # on this GPU (read L*B words + write L*B words), and the latency of ONE resident product
+        # two context figures, outside the timed region: what the library's own 16-bytes-per-lane streaming copy kernel
+        # reaches on the same buffers on this GPU (read L*B words + write L*B words: the achievable ceiling of a
+        # read-once / write-once pass), and the latency of ONE resident product
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
-            c.copy_(a)
+            ntt_amd.dev_stream_copy(c.data_ptr(), a.data_ptr(), 4 * L * B, stream)
         e0.record()
         for _ in range(20):
-            c.copy_(a)
+            ntt_amd.dev_stream_copy(c.data_ptr(), a.data_ptr(), 4 * L * B, stream)
         e1.record()
         torch.cuda.synchronize()
         copy_gbs = 2 * 4 * L * B * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
@@ -527,14 +554,14 @@ def run_single(R, args):
                    "parallelism": f"batch-sharded x{R.world}, no collective"},
         "butterflies_per_unit": 3 * (L // 2) * LOG_L,
         "bytes_per_step": {k: w * 4 * L * B for k, w in words.items()}, "launches_per_step": {k: 1 for k in words},
-        "prof": prof, "roofline_kind": "single",
+        "prof": prof, "roofline_kind": f"single_b{B}",
         "extra": {"us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6, "us_per_mult_batch_1": lat1_us,
                   "pipeline_model": {"what": "a MODEL, not traffic: a two-HBM-passes-per-transform byte count "
                                              "(52 L per product) times the measured rate; the kernels move 32 L",
                                      "model_bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "bytes_per_mult_moved": 32 * L,
                                      "model_GBs_per_gpu": MODEL_BYTES_PER_L * L * (mults / R.world / elapsed) / 1e9,
                                      "model_frac_of_peak": MODEL_BYTES_PER_L * L * (mults / R.world / elapsed) / 1e9 / HBM_PEAK_GBS}},
-        "device_copy_GBs": copy_gbs,
+        "achievable_copy_GBs": copy_gbs,
         "cpu": (lambda: cpu_baseline_main_cc(n, P32)),
     }
     return res
@@ -578,7 +605,7 @@ def run_batch(R, args):
                    "parallelism": f"batch-sharded x{R.world}, no collective"},
         "butterflies_per_unit": 3 * (L // 2) * logL,
         "bytes_per_step": {k: w * 4 * L * nb for k, w in words.items()}, "launches_per_step": {k: 1 for k in words},
-        "prof": prof, "roofline_kind": "batch",
+        "prof": prof, "roofline_kind": f"batch_2p{logL}_b{nb}",
         "extra": {"us_per_mult_per_gpu": elapsed / (nb * args.steps) * 1e6},
         "cpu": (lambda: cpu_baseline_single_prime(n, P32)),
     }
@@ -626,7 +653,7 @@ def run_crt(R, args):
                    "layout": {"prime_groups": sh.gp, "batch_groups": sh.gb},
                    "parallelism": f"{sh.gp} prime group(s) x {sh.gb} batch group(s)"},
         "butterflies_per_unit": 4 * 3 * (L // 2) * 18,
-        "bytes_per_step": bytes_per_step, "launches_per_step": launches, "prof": prof, "roofline_kind": "crt",
+        "bytes_per_step": bytes_per_step, "launches_per_step": launches, "prof": prof, "roofline_kind": f"crt_b{nb}_k{k}",
         "kernels_overlap": k > 1,
         "extra": {"us_per_mult_whole_job": elapsed / (total * args.steps) * 1e6, "exchange_bytes_per_rank": exch},
         "cpu": (lambda: cpu_baseline_main_cc(n, P64, extras=False)),
@@ -714,7 +741,7 @@ def run_fourstep(R, args):
         "config": dict({"workload": f"configs[4]: ONE product of length 2^{logL} (n=2^{logL - 1} per input), prime 469762049, four-step NTT",
                         "p": P32, "log2_len": logL, "parallelism": par}, **cfg_extra),
         "butterflies_per_unit": 3 * (L // 2) * logL,
-        "bytes_per_step": bytes_per_step, "launches_per_step": launches, "prof": prof, "roofline_kind": "fourstep",
+        "bytes_per_step": bytes_per_step, "launches_per_step": launches, "prof": prof, "roofline_kind": f"fourstep_2p{logL}_g{R.world}",
         "extra": {"ms_per_product": elapsed / args.steps * 1e3, "exchange_bytes_per_rank": exch},
         "cpu": (lambda: cpu_baseline_long(logL, P32)),
     }
@@ -750,22 +777,37 @@ def run_rank(args):
             if units and res["butterflies_per_unit"]:
                 out["ns_per_butterfly"] = elapsed / (units * res["butterflies_per_unit"]) * 1e9
             out.update(res["extra"])
+            out["counter_record_key"] = res["roofline_kind"]
             roof, per_kernel = roofline_of(res["prof"], res["bytes_per_step"], res["launches_per_step"], res["roofline_kind"])
             if roof is not None and res.get("kernels_overlap"):
                 # the single-prime products run side by side on forked streams: event times of kernels that share the GPU
                 # are not separable, so the figure is every kernel's moved bytes over the step's wall time
                 tot_b = sum(res["bytes_per_step"].values())
                 step_s = elapsed / args.steps
+                wrec, wstate = recorded_counters("traffic", res["roofline_kind"])
+                wtraffic = (sum(wrec["kernels"].get(k, 0) * res["launches_per_step"].get(k, 1) for k in res["launches_per_step"])
+                            if wrec else None)
+                vrec, vstate = recorded_counters("valu", res["roofline_kind"])
                 roof = {"bound": "hbm", "kernel": "whole step (the primes' kernels overlap on side streams; per-kernel event times are not separable)",
                         "achieved": tot_b / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tot_b / step_s / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "traffic_record": "not recorded for this workload",
+                        "traffic": wtraffic, "traffic_record": wstate,
                         "bytes": "HBM bytes all kernels of a step move (reads + writes, each word once)",
                         "algorithmic_bytes_per_launch": tot_b, "avg_launch_ms": step_s * 1e3, "launches_timed": args.steps}
+                if vrec:
+                    ik, ck = vrec.get("kernels", {}), vrec.get("clock_GHz", {})
+                    busy_s = sum(ik[k] * res["launches_per_step"].get(k, 1) * VALU_CYCLES_PER_INSTRUCTION / (SIMDS * ck[k] * 1e9)
+                                 for k in res["launches_per_step"] if ik.get(k) and ck.get(k))
+                    roof["valu"] = {"record": vstate, "whole_step": {
+                        "wave_instructions_per_step": sum(ik[k] * res["launches_per_step"].get(k, 1) for k in res["launches_per_step"] if ik.get(k)),
+                        "issue_busy_ms_per_step_by_model": busy_s * 1e3, "step_ms": step_s * 1e3, "issue_busy_frac": busy_s / step_s}}
+                    if busy_s / step_s > roof["frac"]:
+                        roof["bound"] = "valu"
                 per_kernel = {k + " (overlapped)": v for k, v in per_kernel.items()}
             if roof is not None:
-                if res.get("device_copy_GBs"):
-                    roof["device_copy_GBs"] = res["device_copy_GBs"]
-                    roof["frac_of_device_copy"] = roof["achieved"] / res["device_copy_GBs"]
+                if res.get("achievable_copy_GBs"):
+                    roof["achievable_copy_GBs"] = res["achievable_copy_GBs"]
+                    roof["frac_of_achievable_copy"] = roof["achieved"] / res["achievable_copy_GBs"]
+                    roof["whole_step"]["frac_of_achievable_copy"] = roof["whole_step"]["achieved"] / res["achievable_copy_GBs"]
                 out["roofline"] = roof
                 out["kernels_ms_per_launch"] = per_kernel
             elif not R.dry:

@@ -204,7 +204,8 @@ int nttx_dev_crt_recombine_u64(const void *d_r0, const void *d_r1, const void *d
  * inverse transform taking rows in bit-reversed order.  zero_hi != 0 (forward): rows from
  * 2^(log_t-1) on are known to be zero and are not read.  Outputs canonical.  Together with a
  * transpose between the processes and length-S products of the rows this is one product of
- * length 2^log_len (no counterpart in the reference, whose arrays stop at 300000, main.cc:228). */
+ * length 2^log_len (no counterpart in the reference, whose arrays stop at 300000, main.cc:228).
+ * Limits: 6 <= log_t <= 9, log_len <= 27, cols a power of two >= 16 that divides col0. */
 int nttx_dev_colpass_u32(void *d_x, int log_len, int log_t, long long col0, int cols, uint32_t p, int inverse,
                          int zero_hi, void *stream);
 
@@ -237,6 +238,11 @@ int nttx_profile_enable(int on);
 int nttx_profile_reset(void);
 /* Waits for the recorded events, then returns accumulated milliseconds and launch count. */
 int nttx_profile_read(int kind, double *total_ms, long long *launches);
+
+/* Measurement aid (no counterpart in the reference): a plain streaming copy of `bytes` bytes on device memory by the
+ * library's own 16-bytes-per-lane kernel, so that a benchmark can quote the passes of a product against the rate a
+ * read-once / write-once kernel reaches on the same GPU.  Pointers 16-byte aligned, bytes a multiple of 16. */
+int nttx_dev_stream_copy(void *d_dst, const void *d_src, size_t bytes, void *stream);
 
 /* Decomposition chosen for a length: writes up to 3 pass sizes (log2) into logt, returns
  * the number of passes, or a negative code. */

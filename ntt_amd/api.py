@@ -57,6 +57,7 @@ _SIGS = [
     ("nttx_plan_info", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     ("nttx_dev_negacyclic_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_plan_info_u64", C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_int)]),
+    ("nttx_dev_stream_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 ]
 
 
@@ -306,6 +307,11 @@ def dev_colpass_u32(d_x: int, log_len: int, log_t: int, col0: int, cols: int, p:
 
 
 KERNEL_KINDS = ("col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv", "split", "crt", "misc")
+
+
+def dev_stream_copy(d_dst: int, d_src: int, nbytes: int, stream: int = 0):
+    """Plain streaming copy by the library's own 16-bytes-per-lane kernel (the achievable-bandwidth yardstick)."""
+    _check(lib().nttx_dev_stream_copy(d_dst, d_src, nbytes, stream))
 
 
 def profile_enable(on: bool = True):

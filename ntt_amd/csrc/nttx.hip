@@ -116,7 +116,9 @@ static bool wide_rows(uint32_t p) {
   return p < (1u << 27) && signed_rows(p) && !narrow_only;
 }
 
-constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 10, kMaxLog = 30;
+// kMaxLog: no prime below 2^31 has 2^28 | p - 1 (the longest direct transform any modulus of these lanes admits is 2^27,
+// modulo 2013265921 = 15 * 2^27 + 1), so the plans stop there.
+constexpr int kMaxRowLog = 11, kMinColLog = 6, kMaxColLog = 9, kMaxLog = 27;
 constexpr int kMinLongRow = 12, kMaxLongRow = 14;   // rows handled by one whole workgroup (longrow kernels)
 
 // NTTX_LONGROW (A/B measurements): bit 0 = long rows behind one column pass (lengths 2^21 .. 2^23), bit 1 = lengths 2^12 .. 2^14 in one pass
@@ -137,12 +139,13 @@ static int decompose(int k, int lt[3]) {
     // (a 2^10-point column pass around 2^14-point rows measured slower at 2^24 than three passes)
     if (k <= 9 + kMaxLongRow) { lt[0] = 9; lt[1] = k - 9; return 2; }
   } else if (k <= kMaxColLog + kMaxRowLog) {
-    lt[0] = k / 2; lt[1] = k - lt[0];
+    lt[0] = std::min(kMaxColLog, k / 2); lt[1] = k - lt[0];
     return 2;
   }
-  // the 512-point row pass is the fused wave-per-row kernel: prefer it while both column passes stay >= 2^6
+  // the 512-point row pass is the fused wave-per-row kernel: prefer it while both column passes stay >= 2^7 (the outer
+  // pass uses the split factor tables, which exist for 2^7 .. 2^9 points)
   int row = (k + 2) / 3; if (row > kMaxRowLog) row = kMaxRowLog;
-  if (row < 9 && k - 9 >= 2 * kMinColLog) row = 9;
+  if (row < 9 && k - 9 >= 2 * 7) row = 9;
   int rem = k - row;
   lt[0] = (rem + 1) / 2; lt[1] = rem - lt[0]; lt[2] = row;
   return 3;
@@ -362,7 +365,7 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
     const int grid = grid_for(A.nrows, capl);
 #define NTTX_LROW_CASE(K) case K: { \
       constexpr int NT_ = LongRowLayout<K>::NTHR, NTM_ = LongRowLayout<K, long_row_wide(K)>::NTHR; \
-      if (MODE != ROW_MUL) hipLaunchKernelGGL((longrow_kernel<K, (MODE == ROW_MUL ? ROW_FWD : MODE), H>), dim3(grid), dim3(NT_), 0, st, A); \
+      if constexpr (MODE != ROW_MUL) { if constexpr (K >= kMinLongRow) hipLaunchKernelGGL((longrow_kernel<K, ROW_FWD, H>), dim3(grid), dim3(NT_), 0, st, A); } \
       else if (H == 9 && wide_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 16, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
       else if (H == 9 && signed_rows(A.ctx.p)) hipLaunchKernelGGL((longrow_mul_kernel<K, 0, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
       else hipLaunchKernelGGL((longrow_mul_kernel<K, H, TWIST>), dim3(grid), dim3(NTM_), 0, st, A); \
@@ -372,10 +375,12 @@ static int launch_row_t(int logT, const RowArgs &A, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return 0;
   }
+  /* (fused products of 2^9 points and more never get here: the kernels above take them) */
 #define NTTX_ROW_CASE(K) case K: { \
     using Lyt = RowLayout<K>; \
     const long long tiles = (A.nrows + Lyt::NT - 1) / Lyt::NT; \
-    hipLaunchKernelGGL((row_kernel<K, MODE, H, TWIST>), dim3(grid_for(tiles, capg)), dim3(WG), 0, st, A); break; }
+    if constexpr (MODE != ROW_MUL || K < 9) hipLaunchKernelGGL((row_kernel<K, MODE, H, TWIST>), dim3(grid_for(tiles, capg)), dim3(WG), 0, st, A); \
+    break; }
   static const int capg = env_int("NTTX_GRID_ROWG", 8192);
   switch (logT) {
     NTTX_ROW_CASE(1) NTTX_ROW_CASE(2) NTTX_ROW_CASE(3) NTTX_ROW_CASE(4) NTTX_ROW_CASE(5) NTTX_ROW_CASE(6)
@@ -390,10 +395,11 @@ template <int MODE>
 static int launch_row_m(int h, int logT, const RowArgs &A, hipStream_t st) {
   return h == 9 ? launch_row_t<MODE, 9>(logT, A, st) : h == 4 ? launch_row_t<MODE, 4>(logT, A, st) : launch_row_t<MODE, 2>(logT, A, st);
 }
+// (an inverse transform runs the forward kernels with the conjugate root's tables, so no caller asks for ROW_INV)
 static int launch_row_raw(int mode, int h, int logT, const RowArgs &A, hipStream_t st) {
   if (mode == ROW_FWD) return launch_row_m<ROW_FWD>(h, logT, A, st);
-  if (mode == ROW_INV) return launch_row_m<ROW_INV>(h, logT, A, st);
-  return launch_row_m<ROW_MUL>(h, logT, A, st);
+  if (mode == ROW_MUL) return launch_row_m<ROW_MUL>(h, logT, A, st);
+  return fail(NTTX_EINVAL, "row pass mode %d unsupported", mode);
 }
 
 // column passes are compiled in their own translation unit (nttx_col.hip)
@@ -444,11 +450,24 @@ static int ew_grid(long long total) { return grid_for((total + 255) / 256, 256 *
 // psi_in[i] as the first pass reads them and c by psi_out[i] as the last pass writes it
 // ws != nullptr: the two transformed copies go to ws[0 .. batch*len) and ws[batch*len .. 2*batch*len) instead of the
 // context's grow-only workspace (the caller has checked the size), and nothing is allocated
+// src64 != nullptr (two-pass plans of linear products): a and b are not read; the first forward pass takes the caller's
+// [batch][nvalid] u64 coefficients instead and reduces them modulo the plan's prime as it loads them (the residue
+// split of main.cc:292-303 without a pass of its own)
+struct Src64 { const uint64_t *a, *b; CoefMod cm; };
+static CoefMod coef_mod(uint64_t pmod) {
+  CoefMod m{pmod, 0};
+  if (pmod) m.mu = (uint64_t)((((unsigned __int128)1) << 64) / pmod);
+  return m;
+}
+// plans whose first forward pass has a u64-source variant: full-line zero-half tiles of 2^6 .. 2^9 points
+static bool src64_ok(const Plan *pl) { return pl->npass == 2 && pl->lt[0] >= 6 && pl->lt[0] <= 9 && pl->logL - pl->lt[0] >= 5; }
 static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c, int batch,
                                hipStream_t st, long long nvalid = 0, const uint32_t *psi_in = nullptr,
                                const uint32_t *psi_out = nullptr, uint32_t *ws = nullptr, int pieces = 0,
-                               int out_slices = 0, long long out_slice_stride = 0) {
+                               int out_slices = 0, long long out_slice_stride = 0, const Src64 *src64 = nullptr) {
   const long long len = 1ll << pl->logL;
+  if (src64 && (!src64_ok(pl) || nvalid <= 0 || 2 * nvalid > len || psi_in || pieces > 0))
+    return fail(NTTX_ERANGE, "u64 source needs a linear product on a two-pass plan");
   if (psi_in && pl->npass > 2) return fail(NTTX_ERANGE, "fused twist needs a one- or two-pass plan");
   // pieces > 0: a, b and c are [pieces][batch][len / pieces] arrays (vector r = the concatenation of its pieces), the
   // layout in which an all-to-all between processes delivers rows and takes them back: the first forward pass reads
@@ -495,6 +514,10 @@ static int dev_cyclic_multiply(Context *cx, Plan *pl, const uint32_t *a, const u
     if (lv == 0 && psi_in) { C.psi = psi_in; C.nvalid = 0; }
     if (lv == 0 && pieces > 0) {
       C.piece_log = piece_log; C.block_stride = len / pieces; C.piece_stride = (long long)batch * C.block_stride; C.nvalid = 0;
+    }
+    if (lv == 0 && src64) {
+      C.in[0] = C.in[1] = nullptr; C.in64[0] = src64->a; C.in64[1] = src64->b; C.cm = src64->cm;
+      C.vec64 = ((nvalid & 1) == 0 && aligned16(src64->a) && aligned16(src64->b)) ? 1 : 0;
     }
     if (int rc = launch_col(cx, false, pl->hclass, pl->lt[lv], C, 2, st)) return rc;
     logN = C.logS;
@@ -609,27 +632,71 @@ static bool crt_side_by_side(size_t words, int ns, int npass) {
   return mode == 1 || (words >= ((size_t)6 << 18) && words <= ((size_t)512 << 18));
 }
 static int crt_products(Context *cx, Plan *const pl[4], int ns, const uint32_t *pa, const uint32_t *pb, uint32_t *const out[4],
-                        int batch, int n, hipStream_t st, int out_slices = 0, long long out_slice_stride = 0) {
+                        int batch, int n, hipStream_t st, int out_slices = 0, long long out_slice_stride = 0,
+                        const Src64 *src64 = nullptr) {
   const long long len = 1ll << pl[0]->logL;
   const size_t words = (size_t)batch * len;
   const bool par = crt_side_by_side(words, ns, pl[0]->npass);
   if (par) {
     if (int rc = cx->wsx.ensure((size_t)(ns - 1) * 2 * words * 4)) return rc;
     HIPCHK(hipEventRecord(cx->fork_ev, st));
-    for (int k = 1; k < ns; ++k) HIPCHK(hipStreamWaitEvent(cx->side[k - 1], cx->fork_ev, 0));
   }
-  for (int k = 0; k < ns; ++k) {
-    hipStream_t sk = (par && k > 0) ? cx->side[k - 1] : st;
-    uint32_t *ws = (par && k > 0) ? cx->wsx.as<uint32_t>() + (size_t)(k - 1) * 2 * words : nullptr;
-    if (int rc = dev_cyclic_multiply(cx, pl[k], pa + (size_t)k * words, pb + (size_t)k * words, out[k], batch, sk, n, nullptr, nullptr, ws,
-                                     0, out_slices, out_slice_stride)) return rc;
+  // From the first fork on, every way out joins the side streams back into the caller's stream (a failed product
+  // included: the next call reuses pa / pb / pc / wsx and must not meet side-stream work still in flight).
+  int forked = 0, rc = 0;
+  for (int k = 0; k < ns && !rc; ++k) {
+    hipStream_t sk = st;
+    uint32_t *ws = nullptr;
+    if (par && k > 0) {
+      sk = cx->side[k - 1];
+      ws = cx->wsx.as<uint32_t>() + (size_t)(k - 1) * 2 * words;
+      const hipError_t e = hipStreamWaitEvent(sk, cx->fork_ev, 0);
+      if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(NTTX_EDEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(e)); break; }
+      forked = k;
+    }
+    rc = dev_cyclic_multiply(cx, pl[k], src64 ? nullptr : pa + (size_t)k * words, src64 ? nullptr : pb + (size_t)k * words, out[k], batch,
+                             sk, n, nullptr, nullptr, ws, 0, out_slices, out_slice_stride, src64);
   }
-  if (par) {
-    for (int k = 1; k < ns; ++k) {
-      HIPCHK(hipEventRecord(cx->join_ev[k - 1], cx->side[k - 1]));
-      HIPCHK(hipStreamWaitEvent(st, cx->join_ev[k - 1], 0));
+  for (int k = 1; k <= forked; ++k) {
+    hipError_t e = hipEventRecord(cx->join_ev[k - 1], cx->side[k - 1]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, cx->join_ev[k - 1], 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(cx->side[k - 1]);       // the join could not be enqueued: wait for the side stream on the host
+      if (!rc) rc = fail(NTTX_EDEVICE, "joining a side stream failed: %s", hipGetErrorString(e));
     }
   }
+  return rc;
+}
+
+// Residue split of a CRT product.  Two-pass lengths read the u64 coefficients inside their first forward pass
+// (fused = true, nothing launched here; NTTX_CRT_FUSED_SPLIT=0 keeps the split as a pass of its own: A/B measurements);
+// other lengths run split_kernel into pa / pb.
+static bool crt_fused_split(const Plan *pl) {
+  static const int on = env_int("NTTX_CRT_FUSED_SPLIT", 1);
+  return on != 0 && src64_ok(pl);
+}
+static int crt_split(Context *cx, Plan *const pl[4], int ns, const uint64_t *d_a, const uint64_t *d_b, int n, uint64_t pmod,
+                     int batch, hipStream_t st, bool *fused) {
+  const long long len = 1ll << pl[0]->logL;
+  *fused = crt_fused_split(pl[0]);
+  if (*fused) return 0;
+  const size_t vec = (size_t)batch * len * 4;
+  if (int rc = cx->pa.ensure(ns * vec)) return rc;
+  if (int rc = cx->pb.ensure(ns * vec)) return rc;
+  SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
+  S.zfill = pl[0]->npass == 1 ? (int)len : n;   // multi-pass products never read the padding
+  S.batch = batch; S.cm = coef_mod(pmod);
+  for (int k = 0; k < ns; ++k) {
+    S.dst[0][k] = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
+    S.dst[1][k] = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
+    S.ctx[k] = pl[k]->ctx;
+  }
+  cx->prof.begin(PK_SPLIT, st);
+  set_vec(S);
+  hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
+  cx->prof.end(st);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -648,31 +715,17 @@ static int dev_crt_multiply(Context *cx, const uint64_t *d_a, const uint64_t *d_
   for (int k = 0; k < ns; ++k) sel[k] = first + k;
   const long long len = 1ll << logL;
   const size_t vec = (size_t)batch * len * 4;
-  if (int rc = cx->pa.ensure(ns * vec)) return rc;
-  if (int rc = cx->pb.ensure(ns * vec)) return rc;
   if (int rc = cx->pc.ensure(ns * vec)) return rc;
   Plan *pl[4];
   for (int k = 0; k < ns; ++k) if (int rc = get_plan(cx, kCrtPrimes[sel[k]], logL, false, &pl[k])) return rc;
-  {
-    SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
-    S.zfill = pl[0]->npass == 1 ? (int)len : n;   // multi-pass products never read the padding
-    S.batch = batch; S.pmod = p;
-    for (int k = 0; k < ns; ++k) {
-      S.dst[0][k] = cx->pa.as<uint32_t>() + (size_t)k * batch * len;
-      S.dst[1][k] = cx->pb.as<uint32_t>() + (size_t)k * batch * len;
-      S.ctx[k] = pl[k]->ctx;
-    }
-    cx->prof.begin(PK_SPLIT, st);
-    set_vec(S);
-    hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
-    cx->prof.end(st);
-    HIPCHK(hipGetLastError());
-  }
+  bool fused = false;
+  if (int rc = crt_split(cx, pl, ns, d_a, d_b, n, p, batch, st, &fused)) return rc;
+  const Src64 src{d_a, d_b, coef_mod(p)};
   CrtArgs A{};
   if (int rc = fill_crt_args(A, p, sel, ns)) return rc;
   uint32_t *outs[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int k = 0; k < ns; ++k) { outs[k] = cx->pc.as<uint32_t>() + (size_t)k * batch * len; A.res[k] = outs[k]; }
-  if (int rc = crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st)) return rc;
+  if (int rc = crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st, 0, 0, fused ? &src : nullptr)) return rc;
   A.out = d_ab; A.nout = 2 * n - 1; A.len = (int)len; A.batch = batch;
   cx->prof.begin(PK_CRT, st);
   set_vec(A);
@@ -693,34 +746,22 @@ static int dev_crt_residues(Context *cx, const uint64_t *d_a, const uint64_t *d_
   if (logL > 21) return fail(NTTX_ERANGE, "length 2^%d exceeds the CRT prime set (2^21)", logL);
   if (prime_mask <= 0 || prime_mask > 15) return fail(NTTX_EINVAL, "prime mask must select 1..4 of the CRT primes");
   const long long len = 1ll << logL;
-  const size_t vec = (size_t)batch * len * 4;
   int sel[4], ns = 0;
   for (int k = 0; k < 4; ++k) if (prime_mask >> k & 1) sel[ns++] = k;
-  if (int rc = cx->pa.ensure(ns * vec)) return rc;
-  if (int rc = cx->pb.ensure(ns * vec)) return rc;
   Plan *pl[4];
   for (int i = 0; i < ns; ++i) if (int rc = get_plan(cx, kCrtPrimes[sel[i]], logL, false, &pl[i])) return rc;
-  SplitArgs S{}; S.src[0] = d_a; S.src[1] = d_b; S.nmod = ns; S.n = n; S.len = (int)len;
-  S.zfill = pl[0]->npass == 1 ? (int)len : n;
-  S.batch = batch; S.pmod = 0;   // no caller modulus here: words are taken as they are (main.cc:300-301)
-  for (int i = 0; i < ns; ++i) {
-    S.dst[0][i] = cx->pa.as<uint32_t>() + (size_t)i * batch * len;
-    S.dst[1][i] = cx->pb.as<uint32_t>() + (size_t)i * batch * len;
-    S.ctx[i] = pl[i]->ctx;
-  }
-  cx->prof.begin(PK_SPLIT, st);
-  set_vec(S);
-  hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, batch, 2), dim3(256), 0, st, S);
-  cx->prof.end(st);
-  HIPCHK(hipGetLastError());
+  bool fused = false;   // no caller modulus here: words are taken as they are (main.cc:300-301)
+  if (int rc = crt_split(cx, pl, ns, d_a, d_b, n, 0, batch, st, &fused)) return rc;
+  const Src64 src{d_a, d_b, coef_mod(0)};
+  const Src64 *sp = fused ? &src : nullptr;
   uint32_t *outs[4] = {nullptr, nullptr, nullptr, nullptr};
   if (slices > 1) {
     const long long sl = len / slices;
     for (int i = 0; i < ns; ++i) outs[i] = d_res + (size_t)i * batch * sl;
-    return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st, slices, (long long)ns * batch * sl);
+    return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st, slices, (long long)ns * batch * sl, sp);
   }
   for (int i = 0; i < ns; ++i) outs[i] = d_res + (size_t)i * batch * len;
-  return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st);
+  return crt_products(cx, pl, ns, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), outs, batch, n, st, 0, 0, sp);
 }
 
 // out[i] = (the integer below M with residues r_k[i]) mod p, i < count (main.cc:323-337 on a slice)
@@ -759,7 +800,7 @@ static int get_slab(Context *cx, uint32_t p, int logL, int logT, long long col0,
   const uint32_t wT = h_powmod(wL, 1ull << (logL - logT), p);
   const uint32_t tinv = h_powmod((uint32_t)((1ull << logT) % p), p - 2, p);
   if (int rc = upload(&sl->tw, stage_table(wT, logT, sl->ctx))) return rc;
-  const bool split_ok = logC >= 13 && (logT == 10 || (logT >= 7 && logT <= 9));   // shapes with a split-table kernel
+  const bool split_ok = logC >= 13 && logT >= 7 && logT <= 9;   // shapes with a split-table kernel
   if (split_ok) {
     // w^((col0 + s) r) with s = h C + l and col0 a multiple of C: (w^C)^((col0/C + h) r) * w^(l r)
     const int c2 = (logC + 1) / 2;
@@ -871,9 +912,52 @@ using namespace nttx;
   NTTX_ENTER(); \
   if (int rc_ = enter_stream(cx, (hipStream_t)(st))) return rc_;
 
+// Host-buffer entry points enqueue copies from and to the caller's arrays on the null stream.  Every way out of such a
+// call waits for that stream: the normal one through finish(), an error in between through the destructor, so no copy
+// touches the caller's memory after the call has returned.
+struct HostCallGuard {
+  bool armed = true;
+  int finish() { armed = false; HIPCHK(hipStreamSynchronize(nullptr)); return 0; }
+  ~HostCallGuard() { if (armed) { (void)hipStreamSynchronize(nullptr); (void)hipGetLastError(); } }
+};
+
 extern "C" {
 
 const char *nttx_last_error(void) { return g_err.c_str(); }
+
+// everything a context owns (also what a half-built one owns after a failed nttx_init)
+static void destroy_context(Context *c) {
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  c->plans.clear();
+  c->slabs.clear();
+  c->twists.clear();
+  if (c->e64) engine64_destroy(c->e64);
+  c->prof.destroy();
+  if (c->ws_event) (void)hipEventDestroy(c->ws_event);
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+  for (int k = 0; k < 3; ++k) {
+    if (c->join_ev[k]) (void)hipEventDestroy(c->join_ev[k]);
+    if (c->side[k]) (void)hipStreamDestroy(c->side[k]);
+  }
+  for (DevBuf *b : {&c->wa, &c->wb, &c->in_a, &c->in_b, &c->pa, &c->pb, &c->pc, &c->outb, &c->tmp, &c->wsx}) b->release();
+  delete c;
+}
+
+static int build_context(Context *c) {
+  HIPCHK(hipSetDevice(c->device));
+  c->e64 = engine64_create();
+  HIPCHK(hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming));
+  // the static scratch: every GPU holds its own copy of the array at its own address, so the address is asked for
+  // with this context's device current, once per context
+  HIPCHK(hipGetSymbolAddress((void **)&c->static_ws, HIP_SYMBOL(g_static_scratch)));
+  HIPCHK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+  for (int k = 0; k < 3; ++k) {
+    HIPCHK(hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->join_ev[k], hipEventDisableTiming));
+  }
+  return 0;
+}
 
 int nttx_init(int device) {
   std::lock_guard<std::mutex> lk(g_init_mu);
@@ -883,43 +967,19 @@ int nttx_init(int device) {
   if (device < 0 || device >= ndev) return fail(NTTX_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
   if (g_ctx && g_ctx->device == device) return 0;
   if (g_ctx) return fail(NTTX_EINVAL, "already initialised on device %d; call nttx_shutdown first", g_ctx->device);
-  HIPCHK(hipSetDevice(device));
-  g_ctx = new Context;
-  g_ctx->device = device;
-  g_ctx->e64 = engine64_create();
-  HIPCHK(hipEventCreateWithFlags(&g_ctx->ws_event, hipEventDisableTiming));
-  // the static scratch: every GPU holds its own copy of the array at its own address, so the address is asked for
-  // with this context's device current, once per context
-  HIPCHK(hipGetSymbolAddress((void **)&g_ctx->static_ws, HIP_SYMBOL(g_static_scratch)));
-  HIPCHK(hipEventCreateWithFlags(&g_ctx->fork_ev, hipEventDisableTiming));
-  for (int k = 0; k < 3; ++k) {
-    HIPCHK(hipStreamCreateWithFlags(&g_ctx->side[k], hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&g_ctx->join_ev[k], hipEventDisableTiming));
-  }
+  // built aside and published only when complete: a failure below leaves the library uninitialised, not half-built
+  Context *c = new Context;
+  c->device = device;
+  if (int rc = build_context(c)) { destroy_context(c); return rc; }
   (void)crt_const();
+  g_ctx = c;
   return 0;
 }
 
 void nttx_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
   if (!g_ctx) return;
-  (void)hipSetDevice(g_ctx->device);
-  (void)hipDeviceSynchronize();
-  g_ctx->plans.clear();
-  g_ctx->slabs.clear();
-  g_ctx->twists.clear();
-  engine64_destroy(g_ctx->e64);
-  g_ctx->prof.destroy();
-  if (g_ctx->ws_event) (void)hipEventDestroy(g_ctx->ws_event);
-  if (g_ctx->fork_ev) (void)hipEventDestroy(g_ctx->fork_ev);
-  for (int k = 0; k < 3; ++k) {
-    if (g_ctx->join_ev[k]) (void)hipEventDestroy(g_ctx->join_ev[k]);
-    if (g_ctx->side[k]) (void)hipStreamDestroy(g_ctx->side[k]);
-  }
-  g_ctx->wsx.release();
-  for (DevBuf *b : {&g_ctx->wa, &g_ctx->wb, &g_ctx->in_a, &g_ctx->in_b, &g_ctx->pa, &g_ctx->pb, &g_ctx->pc, &g_ctx->outb, &g_ctx->tmp})
-    b->release();
-  delete g_ctx;
+  destroy_context(g_ctx);
   g_ctx = nullptr;
 }
 
@@ -936,7 +996,10 @@ void *nttx_host_alloc(size_t bytes) {
 }
 
 void nttx_host_free(void *ptr) {
-  if (ptr) (void)hipHostFree(ptr);
+  if (!ptr) return;
+  std::lock_guard<std::mutex> lock_(g_init_mu);
+  if (g_ctx) (void)hipSetDevice(g_ctx->device);
+  if (hipHostFree(ptr) != hipSuccess) (void)hipGetLastError();
 }
 
 int nttx_path_for(uint64_t p, int n) {
@@ -982,6 +1045,18 @@ int nttx_profile_read(int kind, double *total_ms, long long *launches) {
   cx->prof.fold();
   if (total_ms) *total_ms = cx->prof.ms[kind];
   if (launches) *launches = cx->prof.launches[kind];
+  return 0;
+}
+
+int nttx_dev_stream_copy(void *d_dst, const void *d_src, size_t bytes, void *stream) {
+  NTTX_ENTER();
+  if (!d_dst || !d_src || bytes == 0 || (bytes & 15) || !aligned16(d_dst) || !aligned16(d_src))
+    return fail(NTTX_EINVAL, "stream copy needs 16-byte aligned pointers and a multiple of 16 bytes");
+  const long long n16 = (long long)(bytes >> 4);
+  // one 16-byte word per lane and trip, 8 trips per lane where the buffer is long enough
+  const int grid = grid_for((n16 + 256 * 8 - 1) / (256 * 8), 1 << 20);
+  hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_src, (uint4 *)d_dst, n16);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -1134,11 +1209,11 @@ int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse) {
   NTTX_ENTER_ON(nullptr);
   if (!x || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two");
   if (int rc = cx->in_a.ensure((size_t)len * 4)) return rc;
+  HostCallGuard guard_;
   HIPCHK(hipMemcpyAsync(cx->in_a.ptr, x, (size_t)len * 4, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_ntt_impl(cx, cx->in_a.as<uint32_t>(), len, p, inverse, 0, 1, nullptr)) return rc;
   HIPCHK(hipMemcpyAsync(x, cx->in_a.ptr, (size_t)len * 4, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, int len, uint32_t p) {
@@ -1151,12 +1226,12 @@ int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, 
   if (int rc = cx->pa.ensure(bytes)) return rc;
   if (int rc = cx->pb.ensure(bytes)) return rc;
   if (int rc = cx->pc.ensure(bytes)) return rc;
+  HostCallGuard guard_;
   HIPCHK(hipMemcpyAsync(cx->pa.ptr, a, bytes, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(cx->pb.ptr, b, bytes, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr)) return rc;
   HIPCHK(hipMemcpyAsync(c, cx->pc.ptr, bytes, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, int nout, uint64_t p) {
@@ -1167,8 +1242,9 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
   CrtArgs A{};
   if (int rc = fill_crt_args(A, p)) return rc;
+  for (int k = 0; k < 4; ++k) if (!res[k]) return fail(NTTX_EINVAL, "null residue vector");
+  HostCallGuard guard_;
   for (int k = 0; k < 4; ++k) {
-    if (!res[k]) return fail(NTTX_EINVAL, "null residue vector");
     uint32_t *d = cx->pc.as<uint32_t>() + (size_t)k * len;
     HIPCHK(hipMemcpyAsync(d, res[k], bytes, hipMemcpyHostToDevice, nullptr));
     A.res[k] = d;
@@ -1178,8 +1254,7 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
   hipLaunchKernelGGL(crt_kernel, ew_grid2(nout, 1), dim3(256), 0, 0, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 // Host-buffer entry points: the copies in and out are enqueued on the null stream like the kernels between them and the
@@ -1199,6 +1274,7 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)batch * nout * 4)) return rc;
+  HostCallGuard guard_;
   HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   {
@@ -1213,8 +1289,7 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   hipLaunchKernelGGL((unpad_kernel<uint32_t>), ew_grid2(nout, batch), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint32_t>(), nout, (int)len, batch);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)tout * 4, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 int nttx_poly_multiply_batch_u32(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch) {
@@ -1244,12 +1319,12 @@ int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *a
   if (int rc = cx->in_a.ensure(raw)) return rc;
   if (int rc = cx->in_b.ensure(raw)) return rc;
   if (int rc = cx->outb.ensure(nout * 8)) return rc;
+  HostCallGuard guard_;
   HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_crt_multiply(cx, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->outb.as<uint64_t>(), n, p, 1, nullptr)) return rc;
   HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, nout * 8, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p) {
@@ -1266,6 +1341,7 @@ int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
+  HostCallGuard guard_;
   HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   const ProfHook64 ph = prof_hook(cx);
@@ -1275,8 +1351,7 @@ int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t
                                                     logL, p, 1, n, nullptr, &ph))) return rc;
   if (int rc = fail_from64(engine64_unpad(cx->pc.as<uint64_t>(), cx->outb.as<uint64_t>(), nout, logL, 1, nullptr))) return rc;
   HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 int nttx_dev_negacyclic_multiply_u64(const void *d_a, const void *d_b, void *d_c, int len, uint64_t p, int batch, void *stream) {
@@ -1330,11 +1405,12 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
+  HostCallGuard guard_;
   HIPCHK(hipMemcpyAsync(cx->in_a.ptr, a, raw, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(cx->in_b.ptr, b, raw, hipMemcpyHostToDevice, nullptr));
   {
     SplitArgs S{}; S.src[0] = cx->in_a.as<uint64_t>(); S.src[1] = cx->in_b.as<uint64_t>(); S.nmod = 1; S.n = n; S.len = (int)len;
-    S.zfill = pl->npass == 1 ? (int)len : n; S.batch = 1; S.pmod = 0;
+    S.zfill = pl->npass == 1 ? (int)len : n; S.batch = 1; S.cm = coef_mod(0);
     S.dst[0][0] = cx->pa.as<uint32_t>(); S.dst[1][0] = cx->pb.as<uint32_t>(); S.ctx[0] = pl->ctx;
     set_vec(S);
     hipLaunchKernelGGL(split_kernel, ew_grid2(S.zfill, 1, 2), dim3(256), 0, 0, S);
@@ -1344,8 +1420,7 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   hipLaunchKernelGGL((unpad_kernel<uint64_t>), ew_grid2(nout, 1), dim3(256), 0, 0, cx->pc.as<uint32_t>(), cx->outb.as<uint64_t>(), nout, (int)len, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, (size_t)nout * 8, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return 0;
+  return guard_.finish();
 }
 
 }  // extern "C"

@@ -295,8 +295,10 @@ static int launch_row64_m(const Plan64 *pl, int logT, const RowArgs64 &A, hipStr
   return pl->plo1 ? launch_row64_t<MODE, false, true>(logT, A, st) : launch_row64_t<MODE, false, false>(logT, A, st);
 }
 static int launch_row64(const Plan64 *pl, int mode, int logT, const RowArgs64 &A, hipStream_t st, const ProfHook64 *prof) {
-  if (prof) prof->begin(prof->self, mode == 2 ? NTTX_K_ROW_MUL : mode == 0 ? NTTX_K_ROW_FWD : NTTX_K_ROW_INV, st);
-  const int rc = mode == 0 ? launch_row64_m<0>(pl, logT, A, st) : mode == 1 ? launch_row64_m<1>(pl, logT, A, st) : launch_row64_m<2>(pl, logT, A, st);
+  if (prof) prof->begin(prof->self, mode == 2 ? NTTX_K_ROW_MUL : NTTX_K_ROW_FWD, st);
+  // (mode 1, a decimation-in-time row pass of its own, has no caller: inverse transforms run mode 0 on the conjugate root)
+  const int rc = mode == 0 ? launch_row64_m<0>(pl, logT, A, st) : mode == 2 ? launch_row64_m<2>(pl, logT, A, st)
+                                                                           : fail64(NTTX_EINVAL, "row pass mode %d unsupported", mode);
   if (prof) prof->end(prof->self, st);
   return rc;
 }

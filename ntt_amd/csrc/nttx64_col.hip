@@ -47,8 +47,14 @@ static int launch_col64_fp(int logT, const ColArgs64 &A, int nvec, hipStream_t s
 #define NTTX_COL64FP_CASE(K) case K: \
     if constexpr (!ZHI) { if (A.psi) { hipLaunchKernelGGL((col64_kernel<K, INV, false, false, false, true, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break; } } \
     hipLaunchKernelGGL((col64_kernel<K, INV, false, false, ZHI, false, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break;
+  // (a plain forward pass without the zero half is the inner column pass of a three-pass plan on this class: 2^7 points
+  // and more; 2^6-point passes exist with the zero half, twisted, or inverse)
   switch (logT) {
-    NTTX_COL64FP_CASE(6) NTTX_COL64FP_CASE(7) NTTX_COL64FP_CASE(8) NTTX_COL64FP_CASE(9)
+    case 6:
+      if constexpr (!ZHI) { if (A.psi) { hipLaunchKernelGGL((col64_kernel<6, INV, false, false, false, true, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break; } }
+      if constexpr (INV || ZHI) { hipLaunchKernelGGL((col64_kernel<6, INV, false, false, ZHI, false, true>), dim3(grid, 1, nvec), dim3(512), 0, st, A); break; }
+      else return colfail(NTTX_ERANGE, "column pass of this size unsupported");
+    NTTX_COL64FP_CASE(7) NTTX_COL64FP_CASE(8) NTTX_COL64FP_CASE(9)
     default: return colfail(NTTX_ERANGE, "column pass of this size unsupported");
   }
 #undef NTTX_COL64FP_CASE

@@ -18,11 +18,12 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 static int grid_for(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
 constexpr int kMinColLog = 6;
 
-// Column tile shape: 32 columns (full 128-byte lines) with 512 threads where the tile fits LDS
-// comfortably, 16 columns with 256 threads for the longest column passes.
-template <bool INV, int H, bool ZHI, bool FS2>
+// Column tile shape: 32 columns (full 128-byte lines) wherever the slab has that many, 16 columns for slabs of 16.
+// S64: the input is the caller's u64 coefficients, reduced modulo the pass's prime as the tile is read (ColArgs::in64)
+template <bool INV, int H, bool ZHI, bool FS2, bool S64 = false>
 static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
-  const int wide = (logT <= 9 && A.logS >= 5) ? 1 : 0;
+  static_assert(!S64 || (!INV && ZHI && !FS2), "u64 source: plain zero-half forward passes");
+  const int wide = A.logS >= 5 ? 1 : 0;
   // Few tiles (one product, or a handful): full-line tiles would leave most of the 256 CUs idle while each of the busy
   // ones works through its whole tile, so passes of 2^6 .. 2^9 points switch to tiles of 8 or 4 columns with one radix-8
   // unit per thread and round, until about 256 workgroups exist (one 2^18-point product: 7.8 -> about 2.5 us per pass).
@@ -46,7 +47,7 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   const int g16 = (grid_for(tiles, cap) + 15) / 16 * 16;
   const int grid = g16 <= tiles ? g16 : grid_for(tiles, cap);
 #define NTTX_COL_CASE(K, LC, NT) \
-    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, FS2>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+    hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, FS2, false, 0, S64>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
   if constexpr (!FS2 && !ZHI) {
     if (A.psi) {   // outermost pass of a negacyclic product (full 128-byte tiles only: the caller checks)
 #define NTTX_COLT_CASE(K, NT) \
@@ -63,12 +64,12 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   if constexpr (FS2) {
     switch (logT * 2 + wide) {
       case 15: NTTX_COL_CASE(7, 5, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
-      case 19: NTTX_COL_CASE(9, 5, 512)   case 20: NTTX_COL_CASE(10, 4, 256)   // 512 threads: the 1024-thread shape has no registers left for the second factor
+      case 19: NTTX_COL_CASE(9, 5, 512)   // 512 threads: the 1024-thread shape has no registers left for the second factor
       default: return colfail(NTTX_ERANGE, "split-table column pass of this size unsupported");
     }
     if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
     return 0;
-  }
+  } else {
   if (A.piece_stride) {   // rows in the pieces layout of an all-to-all (full-line tiles of 2^6 .. 2^8-point passes)
     if constexpr (!FS2 && !ZHI) {
 #define NTTX_COLP_CASE(K) \
@@ -96,7 +97,7 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
     static const int seg256 = env_int("NTTX_COL_SEG256", 1);
     if (seg256 && wide && logT == 6 && A.logS >= 6 && !A.psi && tiles >= 1024) {
       const long long t64 = A.nblocks << (A.logS - 6);
-      hipLaunchKernelGGL((col_kernel<6, INV, H, 6, 256, ZHI, false>), dim3(grid_for(t64, cap), 1, nvec), dim3(256), 0, st, A);
+      hipLaunchKernelGGL((col_kernel<6, INV, H, 6, 256, ZHI, false, false, 0, S64>), dim3(grid_for(t64, cap), 1, nvec), dim3(256), 0, st, A);
       if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
       return 0;
     }
@@ -104,7 +105,7 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
   if (lc < 4) {
     if constexpr (!FS2) {
 #define NTTX_COLN_CASE(K, LC, NT) \
-      hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, false>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
+      hipLaunchKernelGGL((col_kernel<K, INV, H, LC, NT, ZHI, false, false, 0, S64>), dim3(grid, 1, nvec), dim3(NT), 0, st, A); break;
       switch (logT * 4 + lc) {                   // one radix-8 unit per thread: 2^(logT + lc - 3) threads
         case 6 * 4 + 3: NTTX_COLN_CASE(6, 3, 64)
         case 7 * 4 + 3: NTTX_COLN_CASE(7, 3, 128)  case 7 * 4 + 2: NTTX_COLN_CASE(7, 2, 64)
@@ -117,17 +118,26 @@ static int launch_col_t(int logT, const ColArgs &A, int nvec, hipStream_t st) {
     if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
     return 0;
   }
+  if constexpr (S64) {   // (the plans that take this route have at least 2^9 columns: full-line tiles only)
+    switch (wide ? logT : 0) {
+      case 6: NTTX_COL_CASE(6, 5, 256)  case 7: NTTX_COL_CASE(7, 5, 256)  case 8: NTTX_COL_CASE(8, 5, 256)  case 9: NTTX_COL_CASE(9, 5, 1024)
+      default: return colfail(NTTX_ERANGE, "column pass of this size has no u64-source variant");
+    }
+    if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
+    return 0;
+  } else {
   switch (logT * 2 + wide) {
     case 12: NTTX_COL_CASE(6, 4, 256)   case 13: NTTX_COL_CASE(6, 5, 256)
     case 14: NTTX_COL_CASE(7, 4, 256)   case 15: NTTX_COL_CASE(7, 5, 256)
     case 16: NTTX_COL_CASE(8, 4, 256)   case 17: NTTX_COL_CASE(8, 5, 256)
     case 18: NTTX_COL_CASE(9, 4, 256)   case 19: NTTX_COL_CASE(9, 5, 1024)
-    case 20: NTTX_COL_CASE(10, 4, 256)
     default: return colfail(NTTX_ERANGE, "column pass of this size unsupported");
   }
-#undef NTTX_COL_CASE
   if (hipGetLastError() != hipSuccess) return colfail(NTTX_EDEVICE, "column kernel launch failed");
   return 0;
+  }   // !S64
+  }   // !FS2
+#undef NTTX_COL_CASE
 }
 template <bool INV, bool ZHI>
 static int launch_col_i(int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
@@ -140,6 +150,12 @@ static int launch_col_i(int h, int logT, const ColArgs &A, int nvec, hipStream_t
 // A.nvalid > 0 selects the zero-padded-half forward variant (needs nvalid <= N/2)
 static int launch_col_sel(bool inv, int h, int logT, const ColArgs &A, int nvec, hipStream_t st) {
   if (logT < kMinColLog || A.logS < 4) return colfail(NTTX_ERANGE, "column pass shape unsupported");
+  if (A.in64[0]) {
+    if (inv || A.nvalid <= 0 || A.fsa || A.psi || A.piece_stride || A.logS < 5 || logT > 9)
+      return colfail(NTTX_ERANGE, "u64 source needs a plain zero-half forward pass of 2^6 .. 2^9 points");
+    return h == 9 ? launch_col_t<false, 9, true, false, true>(logT, A, nvec, st) : h == 4 ? launch_col_t<false, 4, true, false, true>(logT, A, nvec, st)
+                                                                                   : launch_col_t<false, 2, true, false, true>(logT, A, nvec, st);
+  }
   if (inv) return launch_col_i<true, false>(h, logT, A, nvec, st);
   if (A.nvalid > 0) return launch_col_i<false, true>(h, logT, A, nvec, st);
   return launch_col_i<false, false>(h, logT, A, nvec, st);

@@ -1020,6 +1020,29 @@ __global__ void __launch_bounds__(LongRowLayout<LOGT>::NTHR) longrow_kernel(RowA
   }
 }
 
+// One u64 coefficient modulo a 32-bit prime (the residue split of main.cc:292-303): x = hi*2^32 + lo, so
+// x mod m = hi*R + lo mod m with R = 2^32: two Montgomery products, REDC(hi * R^2) and REDC(lo * R), no 64-bit division.
+__device__ __forceinline__ uint32_t split_one(uint64_t x, const PrimeCtx &c) {
+  const uint32_t h = csub(mont_mul_lazy((uint32_t)(x >> 32), c.r2, c.p, c.npinv), c.p);   // hi * 2^32 mod m
+  const uint32_t l = csub(mont_mul_lazy((uint32_t)x, c.one, c.p, c.npinv), c.p);          // lo mod m
+  return csub(h + l, c.p);
+}
+// Coefficients are canonical in the reference's harness (fRead main.cc:78-95 reads residues), but main.cc:300-301
+// accepts any 64-bit word; one at or above the caller's modulus is reduced modulo it first, so that the
+// exactness bound n*(p-1)^2 of the CRT path holds for every input (a rare, divergent branch).  The reduction is
+// Barrett's with mu = floor(2^64 / pmod): q = floor(x * mu / 2^64) is the true quotient or up to two less, so two
+// conditional subtractions finish it (a 64-bit division would pull a long software routine, and its registers,
+// into every kernel that reads coefficients).
+struct CoefMod { uint64_t pmod, mu; };   // pmod == 0: words are taken as they are
+__device__ __forceinline__ uint64_t split_in(uint64_t x, const CoefMod &m) {
+  if (m.pmod != 0 && x >= m.pmod) {
+    x -= __umul64hi(x, m.mu) * m.pmod;
+    if (x >= m.pmod) x -= m.pmod;
+    if (x >= m.pmod) x -= m.pmod;
+  }
+  return x;
+}
+
 // ------------------------------------------------------------------------------------
 // Column kernels: T points at stride S inside blocks of N = T*S words; a tile is
 // T rows x COLS contiguous columns.  The forward pass multiplies point (j', s) by
@@ -1043,6 +1066,11 @@ struct ColArgs {
   // r starts at q * piece_stride + r * block_stride (the layout an all-to-all between processes leaves: [source][row][part])
   int piece_log;
   long long piece_stride, block_stride;
+  // SRC64 kernels (first forward pass of a CRT product): block r is read from the caller's u64 coefficients
+  // in64[z] + r * nvalid (nvalid = coefficients per vector, no padding stored) and reduced modulo this pass's prime
+  const uint64_t *in64[2];
+  CoefMod cm;
+  int vec64;              // every 4-coefficient piece of in64 is 16-byte aligned (nvalid even, bases aligned)
 };
 
 // Each thread moves PER = T*COLS/(4*NTHR) 16-byte pieces of a tile; LPR = COLS/4 lanes cover one
@@ -1057,8 +1085,14 @@ struct ColArgs {
 // they are read, inverse outputs by psi^-i before the canonical store.
 // PIECE: 1 = the input (forward pass), 2 = the output (inverse pass) is in the pieces layout of ColArgs, so that rows
 // handed over by an all-to-all are transformed where they arrive and results leave in the layout the way back sends.
-template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false, bool TWIST = false, int PIECE = 0>
+// SRC64 (zero-half forward passes only): the residue split of a CRT product (main.cc:292-303) happens as the tile is
+// read: the input is the caller's [vectors][nvalid] u64 coefficient array and every word is reduced modulo this pass's
+// prime on its way into LDS, so no split pass writes residues that this pass would read straight back.
+struct Raw64 { ulonglong2 a, b; };
+template <int LOGT, bool INV, int H, int LOGC, int NTHR, bool ZHI = false, bool FS2 = false, bool TWIST = false, int PIECE = 0,
+          bool SRC64 = false>
 __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColArgs A) {
+  static_assert(!SRC64 || (ZHI && !INV && !FS2 && !TWIST && PIECE == 0), "u64 source: plain zero-half forward passes");
   static_assert(!TWIST || (!ZHI && !FS2), "twisted passes read whole vectors and use the plain four-step table");
   static_assert(PIECE == 0 || (!ZHI && !FS2 && !TWIST && PIECE == (INV ? 2 : 1)), "pieces layout: plain passes, input forward / output inverse");
   using L = ColLayout<LOGT, LOGC, NTHR>;
@@ -1140,6 +1174,29 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
       return x;
     }
   };
+  // the same piece from the u64 source: four coefficients of block t_ >> log_tpb, words at or beyond nvalid read as zero
+  const uint64_t *in64 = SRC64 ? A.in64[blockIdx.z] : nullptr;
+  auto load_piece64 = [&](long long t_, int j) -> Raw64 {
+    Raw64 r; r.a = make_ulonglong2(0, 0); r.b = make_ulonglong2(0, 0);
+    const long long ct = t_ & ((1ll << log_tpb) - 1);
+    const long long w0 = ((long long)j << logS) + (ct << LOGC) + c4;   // word index inside the block
+    if (j < T / 2 && w0 < A.nvalid) {
+      const uint64_t *q = in64 + (t_ >> log_tpb) * A.nvalid + w0;
+      if (A.vec64 && w0 + 3 < A.nvalid) {
+        r.a = *reinterpret_cast<const ulonglong2 *>(q); r.b = *reinterpret_cast<const ulonglong2 *>(q + 2);
+      } else {
+        r.a.x = q[0];
+        if (w0 + 1 < A.nvalid) r.a.y = q[1];
+        if (w0 + 2 < A.nvalid) r.b.x = q[2];
+        if (w0 + 3 < A.nvalid) r.b.y = q[3];
+      }
+    }
+    return r;
+  };
+  auto reduce64 = [&](const Raw64 &r) -> uint4 {
+    return make_uint4(split_one(split_in(r.a.x, A.cm), A.ctx), split_one(split_in(r.a.y, A.cm), A.ctx),
+                      split_one(split_in(r.b.x, A.cm), A.ctx), split_one(split_in(r.b.y, A.cm), A.ctx));
+  };
   // Tiles narrower than a 128-byte line: the 2, 4 or 8 tiles that share a line go to workgroups 8 block slots apart,
   // which the dispatcher places on the same XCD, so that XCD's L2 merges their partial-line writes and serves the
   // later partial-line reads (a placement heuristic for speed; any placement is correct).
@@ -1150,13 +1207,17 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     }
     return t0;
   };
-  uint4 nx[PERL];
+  uint4 nx[SRC64 ? 1 : PERL];
+  Raw64 nx64[SRC64 ? PERL : 1];
   uint4 fx[(LAT && INV) ? PERL : 1];   // LAT, inverse: the factors of the pieces in nx
   long long t0 = blockIdx.x;
   if (t0 < ntiles) {
     const long long t = remap(t0), base = tile_base(t);
 #pragma unroll
-    for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, t, j0 + k * RSTEP);
+    for (int k = 0; k < PERL; ++k) {
+      if constexpr (SRC64) nx64[k] = load_piece64(t, j0 + k * RSTEP);
+      else nx[k] = load_piece(base, t, j0 + k * RSTEP);
+    }
     if constexpr (LAT && INV) {
 #pragma unroll
       for (int k = 0; k < PERL; ++k) fx[k] = fs_load(fs_base(t), j0 + k * RSTEP);
@@ -1169,7 +1230,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     __syncthreads();   // previous tile's LDS reads are done
 #pragma unroll
     for (int k = 0; k < PERL; ++k) {
-      uint4 x = nx[k];
+      uint4 x;
+      if constexpr (SRC64) x = reduce64(nx64[k]); else x = nx[k];
       const int j = j0 + k * RSTEP;
       if constexpr (LAT && INV) fs_apply(x, fx[k]);
       else if (INV) fs_mul(x, fbase, j);
@@ -1183,7 +1245,10 @@ __global__ void __launch_bounds__(NTHR, (NTHR == 1024 ? 8 : 1)) col_kernel(ColAr
     if (t0 + gridDim.x < ntiles) {
       const long long tn = remap(t0 + gridDim.x), base = tile_base(tn);
 #pragma unroll
-      for (int k = 0; k < PERL; ++k) nx[k] = load_piece(base, tn, j0 + k * RSTEP);
+      for (int k = 0; k < PERL; ++k) {
+        if constexpr (SRC64) nx64[k] = load_piece64(tn, j0 + k * RSTEP);
+        else nx[k] = load_piece(base, tn, j0 + k * RSTEP);
+      }
       if constexpr (LAT && INV) {
 #pragma unroll
         for (int k = 0; k < PERL; ++k) fx[k] = fs_load(fs_base(tn), j0 + k * RSTEP);
@@ -1250,20 +1315,8 @@ struct SplitArgs {
   int n, len, zfill;
   int vec;                  // n % 4 == 0 and all pointers 16-byte aligned
   int batch;                // vectors per input; gridDim.y strides over them
-  uint64_t pmod;            // != 0: coefficients at or above pmod are first reduced modulo it (the caller's modulus)
+  CoefMod cm;               // pmod != 0: coefficients at or above it are first reduced modulo it (the caller's modulus)
 };
-__device__ __forceinline__ uint32_t split_one(uint64_t x, const PrimeCtx &c) {
-  const uint32_t h = csub(mont_mul_lazy((uint32_t)(x >> 32), c.r2, c.p, c.npinv), c.p);   // hi * 2^32 mod m
-  const uint32_t l = csub(mont_mul_lazy((uint32_t)x, c.one, c.p, c.npinv), c.p);          // lo mod m
-  return csub(h + l, c.p);
-}
-// Coefficients are canonical in the reference's harness (fRead main.cc:78-95 reads residues), but main.cc:300-301
-// accepts any 64-bit word; one at or above the caller's modulus is reduced modulo it first, so that the
-// exactness bound n*(p-1)^2 of the CRT path holds for every input (a rare, divergent branch).
-__device__ __forceinline__ uint64_t split_in(uint64_t x, uint64_t pmod) {
-  if (pmod != 0 && x >= pmod) x %= pmod;
-  return x;
-}
 static __global__ void split_kernel(SplitArgs A) {
  for (long long b = blockIdx.y; b < A.batch; b += gridDim.y) {
   const uint64_t *src = A.src[blockIdx.z] + b * A.n;
@@ -1273,8 +1326,8 @@ static __global__ void split_kernel(SplitArgs A) {
       if (j < A.n) {
         x01 = *reinterpret_cast<const ulonglong2 *>(src + j);
         x23 = *reinterpret_cast<const ulonglong2 *>(src + j + 2);
-        x01.x = split_in(x01.x, A.pmod); x01.y = split_in(x01.y, A.pmod);
-        x23.x = split_in(x23.x, A.pmod); x23.y = split_in(x23.y, A.pmod);
+        x01.x = split_in(x01.x, A.cm); x01.y = split_in(x01.y, A.cm);
+        x23.x = split_in(x23.x, A.cm); x23.y = split_in(x23.y, A.cm);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1288,7 +1341,7 @@ static __global__ void split_kernel(SplitArgs A) {
     continue;
   }
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.zfill; j += gridDim.x * blockDim.x) {
-    const uint64_t x = (j < A.n) ? split_in(src[j], A.pmod) : 0ull;
+    const uint64_t x = (j < A.n) ? split_in(src[j], A.cm) : 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < A.nmod) A.dst[blockIdx.z][k][b * A.len + j] = split_one(x, A.ctx[k]);
@@ -1334,6 +1387,12 @@ static __global__ void twist_kernel(TwistArgs A) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.len; i += gridDim.x * blockDim.x)
       dst[i] = mont_mul(src[i], A.tab[i], A.ctx.p, A.ctx.npinv);
   }
+}
+
+// dst[i] = src[i] on 16-byte words, one word per lane and trip: the streaming copy whose rate is the ceiling a
+// read-once / write-once pass can reach on this part (measurement aid: benchmarks quote the passes against it)
+static __global__ void __launch_bounds__(256) copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // gather the first nout words of every length-len vector (u32 -> u32 or u64)

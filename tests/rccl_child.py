@@ -59,7 +59,7 @@ def main():
                 b[L // 2:] = 0
             fs = FourStepSharded(comm, eng, log_len, P32, log_t=log_t, force_exchange=True)
             da, db = torch.from_numpy(a.view(np.int32)).to(dev), torch.from_numpy(b.view(np.int32)).to(dev)
-            xa, xb = fs.slab_of(da), fs.slab_of(db)
+            xa, xb = fs.slab_of(da).clone(), fs.slab_of(db).clone()     # (with one rank slab_of returns a view; multiply overwrites its slabs)
             xc = fs.multiply(xa, xb, zero_hi=linear)
             got = xc.cpu().numpy().view(np.uint32).reshape(L)
             if log_len <= 24:

@@ -70,12 +70,41 @@ def test_recorded_counters_are_refused_when_kernels_changed(tmp_path, monkeypatc
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     monkeypatch.setattr(bench, "kernel_source_tag", lambda: tag)
-    (prof / "traffic.json").write_text(json.dumps({"kernel_source_tag": tag, "kernels": {"row_mul": 123.0}}))
-    assert bench.recorded_counters("traffic", "row_mul") == (123.0, "current")
-    (prof / "traffic.json").write_text(json.dumps({"kernel_source_tag": "0" * 16, "kernels": {"row_mul": 123.0}}))
-    val, state = bench.recorded_counters("traffic", "row_mul")
+    rec = {"workloads": {"single_b256": {"kernels": {"row_mul": 123.0}}}}
+    (prof / "traffic.json").write_text(json.dumps(dict(rec, kernel_source_tag=tag)))
+    assert bench.recorded_counters("traffic", "single_b256", "row_mul") == (123.0, "current")
+    assert bench.recorded_counters("traffic", "single_b256")[0] == {"kernels": {"row_mul": 123.0}}
+    val, state = bench.recorded_counters("traffic", "crt_b32_k4", "row_mul")
+    assert val is None and state == "not recorded for this workload"
+    (prof / "traffic.json").write_text(json.dumps(dict(rec, kernel_source_tag="0" * 16)))
+    val, state = bench.recorded_counters("traffic", "single_b256", "row_mul")
     assert val is None and state.startswith("stale")
-    assert bench.recorded_counters("valu", "row_mul") == (None, "absent")
+    assert bench.recorded_counters("valu", "single_b256", "row_mul") == (None, "absent")
+
+
+def test_bound_follows_the_counter_records(tmp_path, monkeypatch):
+    """roofline.bound names the VALU when the issue model fills more of the dominant kernel's time than its HBM bytes do."""
+    spec = importlib.util.spec_from_file_location("bench_under_test3", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    tag = bench.kernel_source_tag()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_tag", lambda: tag)
+    kinds = ("col_fwd", "row_mul", "col_inv")
+    (prof / "traffic.json").write_text(json.dumps({"kernel_source_tag": tag, "workloads": {"w": {"kernels": {k: 8.0e8 for k in kinds}}}}))
+    (prof / "valu.json").write_text(json.dumps({"kernel_source_tag": tag, "workloads": {"w": {
+        "kernels": {"col_fwd": 8.0e7, "row_mul": 9.0e7, "col_inv": 5.0e7}, "clock_GHz": {k: 2.0 for k in kinds}}}}))
+    timed = {"col_fwd": (0.18 * 5, 5), "row_mul": (0.2 * 5, 5), "col_inv": (0.12 * 5, 5)}
+    roof, _ = bench.roofline_of(timed, {"col_fwd": 8.05e8, "row_mul": 8.05e8, "col_inv": 5.4e8}, {k: 1 for k in kinds}, "w")
+    busy = 9.0e7 * 4.6 / (1024 * 2.0e9 * 0.2e-3)
+    assert roof["kernel"] == "row_mul" and abs(roof["valu"]["issue_busy_frac"] - busy) < 1e-9
+    assert roof["bound"] == "valu" and roof["frac"] < busy and roof["traffic"] == 8.0e8
+    assert 0.9 < roof["valu"]["whole_step"]["issue_busy_frac"] < 1.0
+    (prof / "valu.json").unlink()
+    roof, _ = bench.roofline_of(timed, {"col_fwd": 8.05e8, "row_mul": 8.05e8, "col_inv": 5.4e8}, {k: 1 for k in kinds}, "w")
+    assert roof["bound"] == "hbm"
 
 
 def test_roofline_arithmetic():

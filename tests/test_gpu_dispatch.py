@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("suite", ["col", "col_big", "rows", "crt", "d64"])
+@pytest.mark.parametrize("suite", ["col", "col_big", "rows", "crt", "d64", "colpass", "layouts", "three_pass_long", "d64_classes"])
 def test_default_dispatch(nttx, oracle, suite):
     sweeps.SUITES[suite](nttx, oracle)
 
@@ -33,13 +33,13 @@ SWITCHES = [
     ({"NTTX_LONGROW": "1"}, ["rows"]),
     ({"NTTX_LONGROW": "2"}, ["rows"]),
     ({"NTTX_GRID_ROW": "3", "NTTX_GRID_ROWG": "2", "NTTX_GRID_LROW": "2"}, ["rows"]),
-    ({"NTTX_TWIST_UNFUSED": "1"}, ["rows", "d64"]),            # negacyclic products through separate twist passes
+    ({"NTTX_TWIST_UNFUSED": "1"}, ["rows", "d64", "d64_classes"]),            # negacyclic products through separate twist passes
     ({"NTTX_CRT_STREAMS": "0"}, ["crt"]),                      # CRT primes on one stream
     ({"NTTX_CRT_STREAMS": "1"}, ["crt"]),                      # ... side by side at every batch
     ({"NTTX_CRT_FOUR": "1"}, ["crt"]),                         # always four primes
     ({"NTTX_CRT_FUSED_SPLIT": "0"}, ["crt"]),                  # residue split as a pass of its own
-    ({"NTTX_FP64": "0"}, ["d64"]),                             # integer classes on the 64-bit lanes
-    ({"NTTX_LONGROW64": "0"}, ["d64"]),                        # 64-bit plans without rows beyond 2^11 points
+    ({"NTTX_FP64": "0"}, ["d64", "d64_classes"]),                             # integer classes on the 64-bit lanes
+    ({"NTTX_LONGROW64": "0"}, ["d64", "d64_classes"]),                        # 64-bit plans without rows beyond 2^11 points
     ({"NTTX_GRID_ROW64": "3", "NTTX_GRID_COL64": "3"}, ["d64"]),
 ]
 
@@ -47,7 +47,7 @@ SWITCHES = [
 @pytest.mark.parametrize("env,suites", SWITCHES, ids=[",".join(f"{k}={v}" for k, v in e.items()) for e, _ in SWITCHES])
 def test_switch_in_child_process(env, suites):
     r = subprocess.run([sys.executable, os.path.join(HERE, "sweeps.py")] + suites, env=dict(os.environ, **env),
-                       capture_output=True, text=True, timeout=110)
+                       capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for s in suites:
         assert f"sweep {s} ok" in r.stdout

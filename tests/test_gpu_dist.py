@@ -23,7 +23,7 @@ def _dev(x):
     (998244353, 14, 7, 64, 16, True),
     (1224736769, 15, 8, 96, 32, True),
     (1004535809, 16, 9, 0, 64, False),
-    (469762049, 17, 10, 112, 16, True),
+    (469762049, 17, 9, 112, 16, True),
 ])
 def test_colpass_matches_cpu_engine(nttx, oracle, p, log_len, log_t, col0, cols, zero_hi):
     from ntt_amd.distributed import HipEngine

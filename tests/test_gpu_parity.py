@@ -696,3 +696,18 @@ def test_device_call_is_graph_capturable(nttx, oracle):
     assert torch.equal(replayed, eager)
     want = oracle.ntt_compute(a[1].cpu().numpy().view(np.uint32), b[1].cpu().numpy().view(np.uint32), p)
     assert np.array_equal(replayed[1].cpu().numpy().view(np.uint32), want)
+
+
+def test_stream_copy(nttx):
+    """The measurement aid nttx_dev_stream_copy (the library's own 16-bytes-per-lane copy kernel) copies exactly."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    for words in (4, 1000 * 4, (1 << 22) + 12):
+        src = torch.randint(0, 1 << 31, (words,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+        dst = torch.zeros_like(src)
+        nttx.dev_stream_copy(dst.data_ptr(), src.data_ptr(), 4 * words, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst)
+    with pytest.raises(nttx.NttxError):
+        nttx.dev_stream_copy(dst.data_ptr(), src.data_ptr(), 12, 0)

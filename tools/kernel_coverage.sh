@@ -42,4 +42,6 @@ timeout -k 10 200 $TRACE -d "$out/harness_int" -- ntt_amd/csrc/nttx_harness_int 
 grep -c "结果正确" "$out/harness.log" "$out/harness_int.log" | tee -a "$out/log.txt"
 
 python3 tools/kernel_coverage.py "$out" > "$out/coverage.md" || exit 1
+# the raw traces are large: keep the summary and the logs only
+rm -rf "$out/main" "$out"/child_[0-9] "$out"/child_[0-9][0-9] "$out/harness" "$out/harness_int" "$out/nttdata" "$out/files"
 head -40 "$out/coverage.md"
