@@ -35,6 +35,7 @@ const char *engine64_error() { return g_err64.c_str(); }
   return fail64(NTTX_EDEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 constexpr int kMaxRow64 = 13, kMinCol64 = 6, kMaxCol64 = 9, kMaxLog64 = 29;
+static int env_int64(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 // Longest row pass for modulus p.  Rows of 2^12 and 2^13 points take one whole workgroup each
 // (NTTX_LONGROW64=0: the plans without them, for A/B runs).  In the lazy class (p < 2^51) a forward
 // pass of k stages on values below 2p ends below 2^(k+1) p, which has to fit 64 bits: k <= 63 - bits(p).
@@ -55,7 +56,11 @@ static int max_row64(uint64_t p, bool fp) {
 int engine64_decompose(int k, uint64_t p, int lt[3], bool fp) {
   const int maxrow = max_row64(p, fp);
   if (k <= maxrow) { lt[0] = k; return 1; }
-  if (k <= kMaxCol64 + maxrow) { lt[0] = std::min(kMaxCol64, k / 2); lt[1] = k - lt[0]; return 2; }
+  if (k <= kMaxCol64 + maxrow) {
+    lt[0] = std::min(kMaxCol64, k / 2);
+    lt[1] = k - lt[0];
+    return 2;
+  }
   int row = std::max((k + 2) / 3, k - 2 * kMaxCol64);
   if (row > 11) row = 11;
   const int rem = k - row;
@@ -261,7 +266,6 @@ static int get_plan64(Engine64 *e, uint64_t p, int logL, bool conj, Plan64 **out
 
 // ---- launches ------------------------------------------------------------------------------
 static int grid_for64(long long tiles, int cap) { return (int)std::max<long long>(1, std::min<long long>(tiles, cap)); }
-static int env_int64(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 template <int MODE, bool SAFE, bool PLO1>
 static int launch_row64_t(int logT, const RowArgs64 &A, hipStream_t st, bool fp = false) {

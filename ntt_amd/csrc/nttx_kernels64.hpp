@@ -538,10 +538,12 @@ struct ColArgs64 {
 // TWIST: outermost pass of a negacyclic product: forward inputs times psi^i as they are read, inverse outputs times
 // psi^-i before the canonical store.
 // FP: the floating-point class; tw and fs hold (w, w/p) pairs, int_in marks integer inputs (first forward pass).
-template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI, bool TWIST = false, bool FP = false>
-__global__ void __launch_bounds__(512, 4) col64_kernel(ColArgs64 A) {
+// NTHR: threads per workgroup.  One tile is 2^LOGT rows x 16 columns; with 2^(LOGT + 1) threads every thread moves four
+// 16-byte pieces and runs one radix-8 unit per round, with 2^LOGT threads eight pieces and two units.
+template <int LOGT, bool INV, bool SAFE, bool PLO1, bool ZHI, bool TWIST = false, bool FP = false, int NTHR = 512>
+__global__ void __launch_bounds__(NTHR, (NTHR == 512 ? 4 : 1)) col64_kernel(ColArgs64 A) {
   static_assert(!TWIST || !ZHI, "twisted passes read whole vectors");
-  constexpr int LOGC = 4, NTHR = 512;
+  constexpr int LOGC = 4;
   using L = ColLayout64<LOGT, LOGC, NTHR>;
   using AR = typename std::conditional<FP, ArithFP, Arith64<SAFE, PLO1>>::type;
   using Tw = typename AR::Tw;
