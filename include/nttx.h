@@ -43,13 +43,24 @@ extern "C" {
                               * are first reduced modulo p, so the bound holds for any input word) */
 #define NTTX_PATH_DIRECT64 2 /* one NTT modulo p itself on 64-bit lanes: 2^31 <= p < 2^62 prime, 2^k | p-1 */
 
-/* Select the GPU of this process and build the context (one process per GPU).
- * No counterpart in the reference (CPU-only program start-up, main.cc:230-270 builds
- * the Barrett/CRT constants once per process; so does this).  It takes ONE device index,
- * not a device list: work is split over GPUs by running one process per GPU (each calls
- * nttx_init with its own device and exchanges data through the building blocks below),
- * never by one process driving several devices. */
+/* Select the GPU of this process and build its context.  No counterpart in the reference (CPU-only program start-up;
+ * main.cc:230-270 builds the Barrett/CRT constants once per process, and so does this).  The usual arrangement is one
+ * process per GPU (each calls nttx_init with its own device and exchanges data through the building blocks below). */
 int nttx_init(int device);
+/* One process driving several GPUs: a context (tables, workspace, streams) per listed device; devices[0] becomes the
+ * current one.  What the reference spreads over host threads (one per CRT modulus, main_pthread.cc:413-428, and one per
+ * index chunk, main_pthread.cc:435-465) a host program can then spread over GPUs: nttx_poly_multiply_batch_u32 deals its
+ * products to all listed devices by itself (one host thread per device), and every other entry point acts on the
+ * current device, which nttx_set_device switches (calls stay serialised on the host; the devices' queues run side by
+ * side).  Calling it again with the same list is a no-op; another list needs nttx_shutdown first. */
+int nttx_init_devices(const int *devices, int ndev);
+/* Number of devices this process initialised (0 before nttx_init). */
+int nttx_device_count(void);
+/* Make `device` (one of the initialised ones) the device later calls act on. */
+int nttx_set_device(int device);
+/* The contiguous share [*lo, *hi) of `batch` independent products that device k of ndev gets from
+ * nttx_poly_multiply_batch_u32 (shares differ by at most one product).  Needs no device. */
+int nttx_deal_batch(int batch, int ndev, int k, int *lo, int *hi);
 void nttx_shutdown(void);
 const char *nttx_last_error(void);
 

@@ -38,6 +38,10 @@ from .api import (  # noqa: F401
     dev_ntt_u32,
     exported_symbols,
     init,
+    init_devices,
+    device_count,
+    set_device,
+    deal_batch,
     lib,
     ntt,
     path_for,
@@ -58,7 +62,7 @@ from . import harness  # noqa: F401
 __all__ = [
     "NttxError", "CRT_PRIMES", "PATH_CRT4", "PATH_DIRECT32", "PATH_DIRECT64", "dev_direct_multiply_u64", "dev_ntt_u64", "poly_multiply_direct64", "reserve_u64", "crt_combine", "cyclic_multiply",
     "crt_prime", "crt_primes_for", "dev_colpass_u32", "dev_stream_copy", "dev_negacyclic_multiply_u32", "dev_negacyclic_multiply_u64", "dev_crt_recombine_u64", "dev_crt_residues_u64", "dev_crt_residues_sliced_u64",
-    "dev_crt_multiply_u64", "dev_cyclic_multiply_u32", "dev_cyclic_multiply_pieces_u32", "dev_poly_multiply_u32", "dev_poly_multiply_u32_static", "host_alloc", "host_free", "dev_ntt_u32", "exported_symbols", "init", "lib", "ntt",
+    "dev_crt_multiply_u64", "dev_cyclic_multiply_u32", "dev_cyclic_multiply_pieces_u32", "dev_poly_multiply_u32", "dev_poly_multiply_u32_static", "host_alloc", "host_free", "dev_ntt_u32", "exported_symbols", "init", "init_devices", "device_count", "set_device", "deal_batch", "lib", "ntt",
     "path_for", "plan_info", "plan_info_u64", "poly_multiply", "poly_multiply_batch", "poly_multiply_crt", "profile_enable", "profile_read", "profile_reset", "KERNEL_KINDS",
     "reserve", "shutdown",
     "harness",

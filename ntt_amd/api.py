@@ -58,6 +58,10 @@ _SIGS = [
     ("nttx_dev_negacyclic_multiply_u64", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     ("nttx_plan_info_u64", C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_int)]),
     ("nttx_dev_stream_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("nttx_init_devices", C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    ("nttx_device_count", C.c_int, []),
+    ("nttx_set_device", C.c_int, [C.c_int]),
+    ("nttx_deal_batch", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 ]
 
 
@@ -104,6 +108,27 @@ def _check(rc):
 
 def init(device: int = 0):
     _check(lib().nttx_init(device))
+
+
+def init_devices(devices):
+    """One process driving several GPUs: a context per listed device, the first one current."""
+    arr = (C.c_int * len(devices))(*devices)
+    _check(lib().nttx_init_devices(arr, len(devices)))
+
+
+def device_count() -> int:
+    return _check(lib().nttx_device_count())
+
+
+def set_device(device: int):
+    _check(lib().nttx_set_device(device))
+
+
+def deal_batch(batch: int, ndev: int, k: int):
+    """The share [lo, hi) of a batch that device k of ndev gets from poly_multiply_batch (needs no device)."""
+    lo, hi = C.c_int(0), C.c_int(0)
+    _check(lib().nttx_deal_batch(batch, ndev, k, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
 def shutdown():

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -204,6 +205,9 @@ struct Context {
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
   DevBuf wsx;                      // their transformed copies (the first prime uses wa / wb)
 };
+// One context per GPU of this process (nttx_init: one; nttx_init_devices: a list).  g_ctx is the context the calls of
+// this process act on (nttx_set_device switches it); nttx_poly_multiply_batch_u32 deals its products over all of them.
+static std::vector<Context *> g_ctxs;
 static Context *g_ctx = nullptr;
 static std::mutex g_init_mu;
 
@@ -916,11 +920,13 @@ using namespace nttx;
 // call waits for that stream: the normal one through finish(), an error in between through the destructor, so no copy
 // touches the caller's memory after the call has returned.
 struct HostCallGuard {
+  Context *cx;
   bool armed = true;
+  explicit HostCallGuard(Context *c) : cx(c) {}
   int finish() { armed = false; HIPCHK(hipStreamSynchronize(nullptr)); return 0; }
   ~HostCallGuard() {
     if (!armed) return;
-    if (g_ctx && g_ctx->side[0]) (void)hipStreamSynchronize(g_ctx->side[0]);   // (the second operand's copy runs there)
+    if (cx && cx->side[0]) (void)hipStreamSynchronize(cx->side[0]);   // (the second operand's copy runs there)
     (void)hipStreamSynchronize(nullptr);
     (void)hipGetLastError();
   }
@@ -976,27 +982,74 @@ static int build_context(Context *c) {
   return 0;
 }
 
+static int init_devices_locked(const int *devices, int ndev) {
+  int have = 0;
+  hipError_t e = hipGetDeviceCount(&have);
+  if (e != hipSuccess || have <= 0) return fail(NTTX_EDEVICE, "no HIP device available: %s", hipGetErrorString(e));
+  if (!devices || ndev < 1 || ndev > 64) return fail(NTTX_EINVAL, "device list must hold 1..64 entries");
+  for (int i = 0; i < ndev; ++i) {
+    if (devices[i] < 0 || devices[i] >= have) return fail(NTTX_EINVAL, "device %d out of range (0..%d)", devices[i], have - 1);
+    // NTTX_REHEARSE_DEVICES=1: the list may name one device several times (a context each), which rehearses the
+    // several-device code path, host threads and dealing included, on a machine with one GPU
+    static const bool rehearse = [] { const char *e_ = getenv("NTTX_REHEARSE_DEVICES"); return e_ && atoi(e_) != 0; }();
+    for (int j = 0; j < i && !rehearse; ++j) if (devices[j] == devices[i]) return fail(NTTX_EINVAL, "device %d listed twice", devices[i]);
+  }
+  if (!g_ctxs.empty()) {
+    bool same = (int)g_ctxs.size() == ndev;
+    for (int i = 0; same && i < ndev; ++i) same = g_ctxs[i]->device == devices[i];
+    if (same) return 0;
+    return fail(NTTX_EINVAL, "already initialised on device %d%s; call nttx_shutdown first", g_ctxs[0]->device,
+                g_ctxs.size() > 1 ? " and others" : "");
+  }
+  // built aside and published only when complete: a failure below leaves the library uninitialised, not half-built
+  std::vector<Context *> built;
+  for (int i = 0; i < ndev; ++i) {
+    Context *c = new Context;
+    c->device = devices[i];
+    built.push_back(c);
+    if (int rc = build_context(c)) { for (Context *q : built) destroy_context(q); return rc; }
+  }
+  (void)crt_const();
+  g_ctxs = built;
+  g_ctx = g_ctxs[0];
+  (void)hipSetDevice(g_ctx->device);
+  return 0;
+}
+
 int nttx_init(int device) {
   std::lock_guard<std::mutex> lk(g_init_mu);
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev <= 0) return fail(NTTX_EDEVICE, "no HIP device available: %s", hipGetErrorString(e));
-  if (device < 0 || device >= ndev) return fail(NTTX_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
-  if (g_ctx && g_ctx->device == device) return 0;
-  if (g_ctx) return fail(NTTX_EINVAL, "already initialised on device %d; call nttx_shutdown first", g_ctx->device);
-  // built aside and published only when complete: a failure below leaves the library uninitialised, not half-built
-  Context *c = new Context;
-  c->device = device;
-  if (int rc = build_context(c)) { destroy_context(c); return rc; }
-  (void)crt_const();
-  g_ctx = c;
+  return init_devices_locked(&device, 1);
+}
+
+int nttx_init_devices(const int *devices, int ndev) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  return init_devices_locked(devices, ndev);
+}
+
+int nttx_device_count(void) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  return (int)g_ctxs.size();
+}
+
+int nttx_set_device(int device) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_ctxs.empty()) return fail(NTTX_ENOINIT, "nttx_init has not been called");
+  for (Context *c : g_ctxs) if (c->device == device) { g_ctx = c; HIPCHK(hipSetDevice(device)); return 0; }
+  return fail(NTTX_EINVAL, "device %d is not among the devices this process initialised", device);
+}
+
+int nttx_deal_batch(int batch, int ndev, int k, int *lo, int *hi) {
+  if (batch < 0 || ndev < 1 || k < 0 || k >= ndev || !lo || !hi) return fail(NTTX_EINVAL, "bad arguments");
+  const int base = batch / ndev, rem = batch % ndev;      // the first `rem` devices take one product more
+  *lo = k * base + std::min(k, rem);
+  *hi = *lo + base + (k < rem ? 1 : 0);
   return 0;
 }
 
 void nttx_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
-  if (!g_ctx) return;
-  destroy_context(g_ctx);
+  for (Context *c : g_ctxs) destroy_context(c);
+  g_ctxs.clear();
   g_ctx = nullptr;
 }
 
@@ -1226,7 +1279,7 @@ int nttx_ntt_u32(uint32_t *x, int len, uint32_t p, int inverse) {
   NTTX_ENTER_ON(nullptr);
   if (!x || len < 1 || (len & (len - 1))) return fail(NTTX_EINVAL, "length must be a power of two");
   if (int rc = cx->in_a.ensure((size_t)len * 4)) return rc;
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   HIPCHK(hipMemcpyAsync(cx->in_a.ptr, x, (size_t)len * 4, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_ntt_impl(cx, cx->in_a.as<uint32_t>(), len, p, inverse, 0, 1, nullptr)) return rc;
   HIPCHK(hipMemcpyAsync(x, cx->in_a.ptr, (size_t)len * 4, hipMemcpyDeviceToHost, nullptr));
@@ -1243,7 +1296,7 @@ int nttx_cyclic_multiply_u32(const uint32_t *a, const uint32_t *b, uint32_t *c, 
   if (int rc = cx->pa.ensure(bytes)) return rc;
   if (int rc = cx->pb.ensure(bytes)) return rc;
   if (int rc = cx->pc.ensure(bytes)) return rc;
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   HIPCHK(hipMemcpyAsync(cx->pa.ptr, a, bytes, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(cx->pb.ptr, b, bytes, hipMemcpyHostToDevice, nullptr));
   if (int rc = dev_cyclic_multiply(cx, pl, cx->pa.as<uint32_t>(), cx->pb.as<uint32_t>(), cx->pc.as<uint32_t>(), 1, nullptr)) return rc;
@@ -1260,7 +1313,7 @@ int nttx_crt_combine_u64(const uint32_t *const res[4], uint64_t *ab, int len, in
   CrtArgs A{};
   if (int rc = fill_crt_args(A, p)) return rc;
   for (int k = 0; k < 4; ++k) if (!res[k]) return fail(NTTX_EINVAL, "null residue vector");
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   for (int k = 0; k < 4; ++k) {
     uint32_t *d = cx->pc.as<uint32_t>() + (size_t)k * len;
     HIPCHK(hipMemcpyAsync(d, res[k], bytes, hipMemcpyHostToDevice, nullptr));
@@ -1291,7 +1344,7 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)batch * nout * 4)) return rc;
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   if (int rc = host_in2(cx, cx->in_a.ptr, a, cx->in_b.ptr, b, raw)) return rc;
   {
     PadArgs P{}; P.src[0] = cx->in_a.as<uint32_t>(); P.src[1] = cx->in_b.as<uint32_t>();
@@ -1308,11 +1361,36 @@ static int host_direct_u32(Context *cx, const uint32_t *a, const uint32_t *b, ui
   return guard_.finish();
 }
 
+// With several devices initialised (nttx_init_devices) the products are dealt to them in contiguous shares
+// (nttx_deal_batch), one host thread per device, each on its own device's context, workspace and null stream: the
+// thread-per-modulus and thread-per-index-chunk split of main_pthread.cc:413-428 / 435-465 with GPUs in place of the
+// threads.  No data moves between the devices: independent products need no exchange.
 int nttx_poly_multiply_batch_u32(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p, int batch) {
   NTTX_ENTER_ON(nullptr);
   if (!a || !b || !ab || n < 1 || batch < 1 || p < 2) return fail(NTTX_EINVAL, "bad arguments");
   if (!direct_ok(p, log2_ceil_len(n))) return fail(NTTX_EINVAL, "modulus %u has no direct transform of this length; use the u64 entry point", p);
-  return host_direct_u32(cx, a, b, ab, n, p, batch);
+  const int ndev = (int)g_ctxs.size();
+  if (ndev == 1 || batch < ndev) return host_direct_u32(cx, a, b, ab, n, p, batch);
+  std::vector<int> rcs(ndev, 0);
+  std::vector<std::string> errs(ndev);
+  std::vector<std::thread> workers;
+  const size_t in_stride = (size_t)n, out_stride = 2 * (size_t)n - 1;
+  for (int k = 0; k < ndev; ++k) {
+    workers.emplace_back([&, k] {
+      int lo = 0, hi = 0;
+      (void)nttx_deal_batch(batch, ndev, k, &lo, &hi);
+      Context *c = g_ctxs[k];
+      if (hi <= lo) return;
+      if (hipSetDevice(c->device) != hipSuccess) { rcs[k] = NTTX_EDEVICE; errs[k] = "hipSetDevice failed"; return; }
+      int rc = enter_stream(c, nullptr);
+      if (!rc) rc = host_direct_u32(c, a + lo * in_stride, b + lo * in_stride, ab + lo * out_stride, n, p, hi - lo);
+      if (rc) { rcs[k] = rc; errs[k] = g_err; }            // (g_err is per thread: carried back to the caller's)
+    });
+  }
+  for (auto &w : workers) w.join();
+  (void)hipSetDevice(cx->device);
+  for (int k = 0; k < ndev; ++k) if (rcs[k]) return fail(rcs[k], "device %d: %s", g_ctxs[k]->device, errs[k].c_str());
+  return 0;
 }
 
 int nttx_poly_multiply_i32(const int32_t *a, const int32_t *b, int32_t *ab, int n, int32_t p) {
@@ -1335,7 +1413,7 @@ int nttx_poly_multiply_crt_u64(const uint64_t *a, const uint64_t *b, uint64_t *a
   if (int rc = cx->in_a.ensure(raw)) return rc;
   if (int rc = cx->in_b.ensure(raw)) return rc;
   if (int rc = cx->outb.ensure(nout * 8)) return rc;
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   if (int rc = host_in2(cx, cx->in_a.ptr, a, cx->in_b.ptr, b, raw)) return rc;
   if (int rc = dev_crt_multiply(cx, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->outb.as<uint64_t>(), n, p, 1, nullptr)) return rc;
   HIPCHK(hipMemcpyAsync(ab, cx->outb.ptr, nout * 8, hipMemcpyDeviceToHost, nullptr));
@@ -1356,7 +1434,7 @@ int nttx_poly_multiply_direct_u64(const uint64_t *a, const uint64_t *b, uint64_t
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   if (int rc = host_in2(cx, cx->in_a.ptr, a, cx->in_b.ptr, b, raw)) return rc;
   const ProfHook64 ph = prof_hook(cx);
   if (int rc = fail_from64(engine64_pad(cx->e64, cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), cx->pa.as<uint64_t>(),
@@ -1419,7 +1497,7 @@ int nttx_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, i
   if (int rc = cx->pb.ensure(vec)) return rc;
   if (int rc = cx->pc.ensure(vec)) return rc;
   if (int rc = cx->outb.ensure((size_t)nout * 8)) return rc;
-  HostCallGuard guard_;
+  HostCallGuard guard_(cx);
   if (int rc = host_in2(cx, cx->in_a.ptr, a, cx->in_b.ptr, b, raw)) return rc;
   if (crt_fused_split(pl)) {     // two-pass lengths: the first column pass reads the u64 coefficients itself
     const Src64 src{cx->in_a.as<uint64_t>(), cx->in_b.as<uint64_t>(), coef_mod(0)};

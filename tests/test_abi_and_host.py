@@ -186,3 +186,21 @@ def test_shard_range():
             assert cover == list(range(total))
     assert [prime_owner(k, 4) for k in range(4)] == [0, 1, 2, 3]
     assert [prime_owner(k, 2) for k in range(4)] == [0, 1, 0, 1]
+
+
+def test_batch_dealing_matches_the_rank_sharding():
+    """nttx_deal_batch (how nttx_poly_multiply_batch_u32 deals products to the devices of nttx_init_devices) gives the
+    shares ntt_amd.sharding.shard_range gives ranks: contiguous, covering, sizes differing by at most one."""
+    import ntt_amd
+    from ntt_amd.sharding import shard_range
+    for batch in (0, 1, 2, 7, 8, 9, 100, 4096, 70001):
+        for ndev in (1, 2, 3, 4, 8):
+            shares = [ntt_amd.deal_batch(batch, ndev, k) for k in range(ndev)]
+            assert shares == [tuple(shard_range(batch, k, ndev)) for k in range(ndev)]
+            assert shares[0][0] == 0 and shares[-1][1] == batch
+            assert all(shares[k][1] == shares[k + 1][0] for k in range(ndev - 1))
+            sizes = [hi - lo for lo, hi in shares]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ntt_amd.NttxError):
+        ntt_amd.deal_batch(10, 2, 2)
+    assert ntt_amd.device_count() == 0 or ntt_amd.device_count() >= 1      # callable without a device
