@@ -45,7 +45,7 @@ P64 = 1337006139375617       # harness id 4's modulus (test.o:11)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
 CLOCK_GHZ = 2.4              # MI355X peak engine clock
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
-RAMP_STEPS = 50              # untimed steps always run before the timed region of the headline workload (clock ramp)
+RAMP_MS = 30.0               # untimed back-to-back load run before every timed region (clock ramp)
 EVENT_EVERY = 4              # steps of the timed region whose kernels are bracketed by HIP events: every 4th
 MODEL_BYTES_PER_L = 52       # two-passes-per-transform model: 13 L words per single-prime product
 KERNEL_SOURCES = ("nttx_kernels.hpp", "nttx_arith.hpp", "nttx.hip", "nttx_col.hip", "nttx_launch.hpp")
@@ -391,6 +391,21 @@ class Rank:
         for _ in range(warmup):
             step()
         self.sync()
+        # MI355X needs some 20-30 ms of load to reach the clocks it then holds; a host-side check or a short warm-up leaves
+        # it below them, so the warm-up is topped up with untimed steps until RAMP_MS of back-to-back load have run
+        # (the count comes from four measured steps, maximum over the ranks, so every rank runs the same number of steps:
+        # steps may hold collectives)
+        self.ramp_steps = 0
+        if not self.dry:
+            t_ramp = time.perf_counter()
+            for _ in range(4):
+                step()
+            self.sync()
+            per_step = self.max_over_ranks((time.perf_counter() - t_ramp) / 4)
+            self.ramp_steps = max(4, min(4000, int(RAMP_MS * 1e-3 / max(per_step, 1e-6)) + 1))
+            for _ in range(self.ramp_steps - 4):
+                step()
+            self.sync()
         if events:
             ntt_amd.profile_reset()
         self.barrier()
@@ -512,10 +527,8 @@ def run_single(R, args):
         want = po.Oracle().ntt_compute(a[0].cpu().numpy().view(np.uint32), b[0].cpu().numpy().view(np.uint32), P32)
         if not np.array_equal(c[0].cpu().numpy().view(np.uint32), want):
             raise SystemExit(json.dumps({"error": "GPU result differs from the oracle"}))
-    # the host-side check leaves the GPU idle long enough for its clocks to drop; MI355X takes some 20-30 ms of load to
-    # reach its steady clocks, so the warm-up is topped up to RAMP_STEPS steps
-    ramp = max(0, RAMP_STEPS - args.warmup)
-    elapsed = R.timed(step, args.steps, args.warmup + ramp, events=not args.no_events)
+    elapsed = R.timed(step, args.steps, args.warmup, events=not args.no_events)
+    ramp = R.ramp_steps
     prof = ntt_amd.profile_read() if not args.no_events else {}
 
     copy_gbs = lat1_us = None
@@ -639,9 +652,15 @@ def run_crt(R, args):
     prof = ntt_amd.profile_read() if not args.no_events else {}
     k = len(sh.own)                               # primes this rank transforms for
     sl = L // sh.gp                               # indices this rank recombines per product
-    bytes_per_step = {"col_fwd": 12 * L * nb * k, "row_mul": 12 * L * nb * k, "col_inv": 8 * L * nb * k,
-                      "split": (16 + 8 * k) * n * nb, "crt": (16 + 8) * sl * nb}
-    launches = {"col_fwd": k, "row_mul": k, "col_inv": k, "split": 1, "crt": 1}
+    # the residue split happens inside the first column pass (which then reads the u64 coefficients: 16 n + 8 L bytes per
+    # product and prime) unless the library was told to run it as a pass of its own (a split kernel shows in the timings)
+    fused = not (prof.get("split") and prof["split"][1] > 0) if prof else True
+    bytes_per_step = {"col_fwd": (16 if fused else 12) * L * nb * k, "row_mul": 12 * L * nb * k, "col_inv": 8 * L * nb * k,
+                      "crt": (16 + 8) * sl * nb}
+    launches = {"col_fwd": k, "row_mul": k, "col_inv": k, "crt": 1}
+    if not fused:
+        bytes_per_step["split"] = (16 + 8 * k) * n * nb
+        launches["split"] = 1
     exch = int(nb * L * 4 * k * (sh.gp - 1) / sh.gp)
     return {
         "metric": "poly-mults/sec at n=2^17 coefficients modulo a 51-bit prime (four 32-bit NTT primes + CRT)", "unit": "poly-mults/s",
@@ -770,8 +789,7 @@ def run_rank(args):
                    "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                    "scaling": res["scaling"], "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
                    "config": res["config"], "workload": args.workload, "backend": R.backend, "rccl_ranks": R.rccl_ranks}
-            if "clock_ramp_steps" in res:
-                out["clock_ramp_steps"] = res["clock_ramp_steps"]
+            out["clock_ramp_steps"] = getattr(R, "ramp_steps", 0)
             if R.rehearsal and R.world > 1:
                 out["rehearsal"] = "NTTX_BENCH_ONE_DEVICE=1: every rank ran on GPU 0; not a multi-GPU measurement"
             if units and res["butterflies_per_unit"]:

@@ -230,6 +230,16 @@ class HipEngine:
         self._api.dev_crt_residues_u64(a.data_ptr(), b.data_ptr(), res.data_ptr(), n, prime_mask, batch, self._stream())
         return res
 
+    def crt_multiply(self, a, b, n, p):
+        """a, b: [batch][n] int64 -> [batch][2n-1] int64: the whole four-prime product on one GPU in one call (residue
+        split, products, recombination: main.cc:286-338)."""
+        t = self._t
+        self._chk(a, t.int64)
+        self._chk(b, t.int64)
+        out = t.empty((a.shape[0], 2 * n - 1), dtype=t.int64, device=a.device)
+        self._api.dev_crt_multiply_u64(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, a.shape[0], self._stream())
+        return out
+
     def crt_residues_sliced(self, a, b, n, prime_mask, slices):
         """The same residues as [slices][primes in mask][batch][len / slices] (slice q = indices q*len/slices ..): the
         send buffer of the exchange between the processes that share the primes, written in place by the last pass.
@@ -332,6 +342,11 @@ class CrtSharded:
         from . import api
         api.crt_primes_for(p, n)
         if gp == 1 and not self.force_exchange:
+            if hasattr(self.engine, "crt_multiply"):
+                # one rank owns every prime and the whole index range: the single-GPU entry point does all of it in one
+                # call (the first column pass reads the u64 coefficients itself, the residues never leave the library's
+                # workspace); [nb][2n-1], the meaningful indices, with or without gather
+                return self.engine.crt_multiply(a, b, n, p)
             res = self.engine.crt_residues(a, b, n, self.mask)          # [nown][nb][len]
             full = self.engine.crt_recombine([res[k] for k in range(CRT_PRIME_COUNT)], p)
             return full[:, : 2 * n - 1] if gather else full

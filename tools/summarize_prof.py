@@ -32,7 +32,7 @@ command = open(os.path.join(src, "command.txt")).read().strip() if os.path.exist
 
 
 def short(name):
-    return name.split("(")[0].replace("void nttx::", "")
+    return name.split("(")[0].replace("void ", "").replace("nttx::", "")
 
 
 def kind_of(name):
