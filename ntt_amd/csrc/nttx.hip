@@ -1126,8 +1126,9 @@ int nttx_dev_stream_copy(void *d_dst, const void *d_src, size_t bytes, void *str
   if (!d_dst || !d_src || bytes == 0 || (bytes & 15) || !aligned16(d_dst) || !aligned16(d_src))
     return fail(NTTX_EINVAL, "stream copy needs 16-byte aligned pointers and a multiple of 16 bytes");
   const long long n16 = (long long)(bytes >> 4);
-  // one 16-byte word per lane and trip, 8 trips per lane where the buffer is long enough
-  const int grid = grid_for((n16 + 256 * 8 - 1) / (256 * 8), 1 << 20);
+  // one 16-byte word per lane, one workgroup per 4 KB: measured fastest on MI355X (6.0 TB/s on 2 x 268 MB against
+  // 4.3 - 5.1 TB/s with 4 .. 64 words per lane)
+  const int grid = grid_for((n16 + 255) / 256, 1 << 22);
   hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_src, (uint4 *)d_dst, n16);
   HIPCHK(hipGetLastError());
   return 0;

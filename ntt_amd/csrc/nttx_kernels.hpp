@@ -1389,7 +1389,7 @@ static __global__ void twist_kernel(TwistArgs A) {
   }
 }
 
-// dst[i] = src[i] on 16-byte words, one word per lane and trip: the streaming copy whose rate is the ceiling a
+// dst[i] = src[i] on 16-byte words, one word per lane (one trip wherever the grid covers the buffer): the streaming copy whose rate is the ceiling a
 // read-once / write-once pass can reach on this part (measurement aid: benchmarks quote the passes against it)
 static __global__ void __launch_bounds__(256) copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
