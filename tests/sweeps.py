@@ -357,6 +357,7 @@ def suite_layouts(nttx, O):
     for p, k in ((P9, 24), (P2, 24), (P4B, 24), (P2B, 24)):
         cyclic(nttx, O, p, k, 1, seed=k)
         linear(nttx, O, p, (1 << (k - 1)) - 3, 1, seed=k + 1)
+    cyclic(nttx, O, P9, 24, 2, seed=99)      # two three-pass products per call (the workspace holds one padded copy per vector)
 
 
 def suite_three_pass_long(nttx, O):

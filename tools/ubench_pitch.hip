@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
 
 template <int NTHR, int MODE>   // MODE 0: read+write, 1: read only, 2: write only
@@ -78,7 +79,22 @@ int main() {
              2 * gb / m0 * 1e3, gb / m1 * 1e3, gb / m2 * 1e3, 2 * gb / m3 * 1e3);
     }
   }
-  for (int logc : {12, 15, 16}) {          // columns per row: 2^21, 2^24, 2^25-point vectors
+  // the outer pass of a three-pass product: tiles of 512 (or 256) rows whose rows lie 2^16 / 2^17 words apart, several
+  // vectors per launch (more than the memory-side cache holds), input and output pitch chosen separately
+  for (int logc : {16, 17}) {
+    const long long cols = 1ll << logc;
+    const int nvec = logc == 16 ? 4 : 2;
+    const double gbb = 512.0 * cols * 4 / 1e9 * nvec;
+    const long long pads[][2] = {{0, 0}, {0, 32}, {32, 0}, {32, 32}, {0, 96}, {96, 0}, {0, 544}, {544, 0}};
+    for (auto &pd : pads) {
+      const long long pin = cols + pd[0], pout = cols + pd[1];
+      if (512 * std::max(pin, pout) * nvec > cap) continue;
+      double m0 = timeit([&] {
+        for (int v = 0; v < nvec; ++v) big_copy<0><<<(int)(cols / 32), 1024>>>(a + v * 512 * pin, b + v * 512 * pout, cols / 32, pin, pout); });
+      printf("%d vectors of 512 rows x 2^%d words, pitch in +%lld out +%lld: r+w %7.1f GB/s\n", nvec, logc, pd[0], pd[1], 2 * gbb / m0 * 1e3);
+    }
+  }
+  for (int logc : {12, 15, 16, 17}) {      // columns per row: 2^21, 2^24, 2^25, 2^26-point vectors (the last one beyond the memory-side cache)
     const long long cols = 1ll << logc;
     const double gbb = 512.0 * cols * 4 / 1e9;
     for (long long pad : {0ll, 32ll, 96ll, 544ll}) {
