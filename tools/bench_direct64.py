@@ -20,7 +20,7 @@ for arg in sys.argv[1:]:
     for _ in range(30): step()
     torch.cuda.synchronize()
     ntt_amd.profile_reset(); ntt_amd.profile_enable(True)
-    K = 40
+    K = int(os.environ.get("STEPS", 40))     # (STEPS: long runs for power traces)
     t0 = time.perf_counter()
     for _ in range(K): step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
