@@ -498,6 +498,49 @@ def roofline_of(prof, bytes_per_step, launches_per_step, workload=None):
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
+def power_sample(step, torch, settle_s=1.5):
+    """Socket power and shader clocks while `step` runs back to back (a context figure, outside the timed region): the
+    step is enqueued for settle_s seconds, then `amd-smi metric --power --clock` runs as a child process while more
+    steps keep the GPU busy.  None where the tool is absent or its output has another shape."""
+    import re
+    import shutil
+    import subprocess
+    if not shutil.which("amd-smi"):
+        return None
+    try:
+        t_end = time.perf_counter() + settle_s
+        while time.perf_counter() < t_end:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+        proc = subprocess.Popen(["amd-smi", "metric", "-g", "0", "--power", "--clock"], stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL, text=True)
+        t_end = time.perf_counter() + 30.0
+        while proc.poll() is None and time.perf_counter() < t_end:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+        if proc.poll() is None:
+            proc.kill()
+            return None
+        text = proc.stdout.read()
+        watts = [int(x) for x in re.findall(r"SOCKET_POWER: (\d+) W", text)]
+        gfx = text.split("GFX_0:")[1].split("MEM_0:")[0] if "GFX_0:" in text and "MEM_0:" in text else ""
+        clocks = [int(x) for x in re.findall(r"^\s+CLK: (\d+) MHz", gfx, re.M)]
+        cap = None
+        if shutil.which("rocm-smi"):
+            m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)",
+                          subprocess.run(["rocm-smi", "-d", "0", "--showmaxpower"], capture_output=True, text=True, timeout=30).stdout)
+            cap = float(m.group(1)) if m else None
+        if not watts or not clocks:
+            return None
+        return {"socket_W": watts[0], "cap_W": cap, "shader_MHz_per_xcd": clocks, "shader_MHz_max": 2400,
+                "what": f"one amd-smi sample of GPU 0 taken while the step ran back to back (after {settle_s} s of load), outside "
+                        "the timed region: at the cap the part lowers its clock, and the VALU fractions refer to that clock"}
+    except Exception:                                      # noqa: BLE001  (a reported extra, never fatal)
+        return None
+
+
 def rand_padded(torch, gen, dev, rows, n, length, p):
     x = torch.zeros((rows, length), dtype=torch.int32, device=dev)
     x[:, :n] = torch.randint(0, p, (rows, n), generator=gen, device=dev, dtype=torch.int64).to(torch.int32)
@@ -531,7 +574,7 @@ def run_single(R, args):
     ramp = R.ramp_steps
     prof = ntt_amd.profile_read() if not args.no_events else {}
 
-    copy_gbs = lat1_us = None
+    copy_gbs = lat1_us = power = None
     if R.rank == 0 and not args.no_context:
         # two context figures, outside the timed region: what the library's own 16-bytes-per-lane streaming copy kernel
         # reaches on the same buffers on this GPU (read L*B words + write L*B words: the achievable ceiling of a
@@ -553,6 +596,8 @@ def run_single(R, args):
             ntt_amd.dev_poly_multiply_u32(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, P32, 1, stream)
         torch.cuda.synchronize()
         lat1_us = (time.perf_counter() - t1) / 200 * 1e6
+        if R.world == 1:
+            power = power_sample(step, torch)
     # HBM words each kernel moves per product (u32 words of length L moved once): col_fwd reads the n = L/2
     # coefficients of a and b (their zero padding is never read) and writes both transformed copies (1 + 2 = 3 L words),
     # row_mul reads both copies and writes the product rows (3 L), col_inv reads and writes the product (2 L)
@@ -568,7 +613,7 @@ def run_single(R, args):
         "butterflies_per_unit": 3 * (L // 2) * LOG_L,
         "bytes_per_step": {k: w * 4 * L * B for k, w in words.items()}, "launches_per_step": {k: 1 for k in words},
         "prof": prof, "roofline_kind": f"single_b{B}",
-        "extra": {"us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6, "us_per_mult_batch_1": lat1_us,
+        "extra": {"us_per_mult_per_gpu": elapsed / (B * args.steps) * 1e6, "us_per_mult_batch_1": lat1_us, "power": power,
                   "pipeline_model": {"what": "a MODEL, not traffic: a two-HBM-passes-per-transform byte count "
                                              "(52 L per product) times the measured rate; the kernels move 32 L",
                                      "model_bytes_per_mult_52L": MODEL_BYTES_PER_L * L, "bytes_per_mult_moved": 32 * L,
